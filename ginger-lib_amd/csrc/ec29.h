@@ -1,0 +1,111 @@
+// ec29.h -- short-Weierstrass curve arithmetic in homogeneous projective coordinates
+// (X:Y:Z), infinity <=> Z == 0, over the fields of fp29.h.  Formulas are the ones the reference
+// uses for MNT4/6-753 G1 and G2 (algebra/src/curves/models/short_weierstrass_projective.rs):
+//   double_in_place  :444-479  (dbl-2007-bl)
+//   add_assign_mixed :481-519  (madd-1998-cmo, with the explicit infinity / P==Q branches)
+//   add_assign       :574-617  (add-1998-cmo-2)
+// The projective triple an MSM returns depends on the order of additions; only the affine image
+// is canonical, so the device is free to order additions for parallelism.
+#pragma once
+#include "fp29.h"
+
+namespace gh {
+
+// ----- curve policies: base-field tower + multiplication by the curve coefficient a
+struct Mnt4G1 {  // y^2 = x^3 + 2x + b over p4       (curves/mnt4753/g1.rs:19-50)
+    typedef F1<P4> F;
+    static GH_HD F::T mul_by_a(const F::T& z) { return fp_dbl<P4>(z); }
+};
+struct Mnt6G1 {  // y^2 = x^3 + 11x + b over p6      (curves/mnt6753/g1.rs:19-52)
+    typedef F1<P6> F;
+    static GH_HD F::T mul_by_a(const F::T& z) { return fp_mul_small<P6, 11>(z); }
+};
+struct Mnt4G2 {  // twist over Fq2, a' = (26, 0)     (curves/mnt4753/g2.rs:57-75, mul_by_a :113-118)
+    typedef F2<P4, 13> F;
+    static GH_HD F::T mul_by_a(const F::T& z) { return F::T{fp_mul_small<P4, 26>(z.c0), fp_mul_small<P4, 26>(z.c1)}; }
+};
+struct Mnt6G2 {  // twist over Fq3, a' = (0, 0, 11)  (curves/mnt6753/g2.rs:71-100, mul_by_a :149-155)
+    typedef F3<P6, 11> F;
+    static GH_HD F::T mul_by_a(const F::T& z) {
+        return F::T{fp_mul_small<P6, 121>(z.c1), fp_mul_small<P6, 121>(z.c2), fp_mul_small<P6, 11>(z.c0)};
+    }
+};
+
+template <class C> struct Proj {
+    typename C::F::T x, y, z;
+};
+template <class C> struct Aff {
+    typename C::F::T x, y;
+};
+
+template <class C> GH_HD Proj<C> proj_zero() {  // (0, 1, 0)   swp.rs:372-378
+    typedef typename C::F F;
+    return Proj<C>{F::zero(), F::one(), F::zero()};
+}
+template <class C> GH_HD bool proj_is_zero(const Proj<C>& p) { return C::F::is_zero(p.z); }
+
+template <class C> GH_HD Proj<C> proj_dbl(const Proj<C>& p) {
+    typedef typename C::F F;
+    if (proj_is_zero(p)) return p;
+    typename F::T xx = F::sqr(p.x);
+    typename F::T zz = F::sqr(p.z);
+    typename F::T w = F::add(C::mul_by_a(zz), F::add(xx, F::dbl(xx)));
+    typename F::T s = F::dbl(F::mul(p.y, p.z));
+    typename F::T sss = F::mul(F::sqr(s), s);
+    typename F::T r = F::mul(p.y, s);
+    typename F::T rr = F::sqr(r);
+    typename F::T b = F::sub(F::sub(F::sqr(F::add(p.x, r)), xx), rr);
+    typename F::T h = F::sub(F::sqr(w), F::dbl(b));
+    Proj<C> o;
+    o.x = F::mul(h, s);
+    o.y = F::sub(F::mul(w, F::sub(b, h)), F::dbl(rr));
+    o.z = sss;
+    return o;
+}
+
+// p += q, q affine and NOT the point at infinity (callers drop infinity bases: swp.rs:482-483)
+template <class C> GH_HD Proj<C> proj_madd(const Proj<C>& p, const Aff<C>& q) {
+    typedef typename C::F F;
+    if (proj_is_zero(p)) return Proj<C>{q.x, q.y, F::one()};
+    typename F::T v = F::mul(q.x, p.z);
+    typename F::T u = F::mul(q.y, p.z);
+    if (F::eq(u, p.y) && F::eq(v, p.x)) return proj_dbl<C>(p);
+    u = F::sub(u, p.y);
+    typename F::T uu = F::sqr(u);
+    v = F::sub(v, p.x);
+    typename F::T vv = F::sqr(v);
+    typename F::T vvv = F::mul(v, vv);
+    typename F::T r = F::mul(vv, p.x);
+    typename F::T a = F::sub(F::sub(F::mul(uu, p.z), vvv), F::dbl(r));
+    Proj<C> o;
+    o.x = F::mul(v, a);
+    o.y = F::sub(F::mul(u, F::sub(r, a)), F::mul(vvv, p.y));
+    o.z = F::mul(vvv, p.z);
+    return o;
+}
+
+template <class C> GH_HD Proj<C> proj_add(const Proj<C>& p, const Proj<C>& q) {
+    typedef typename C::F F;
+    if (proj_is_zero(p)) return q;
+    if (proj_is_zero(q)) return p;
+    typename F::T y1z2 = F::mul(p.y, q.z);
+    typename F::T x1z2 = F::mul(p.x, q.z);
+    typename F::T z1z2 = F::mul(p.z, q.z);
+    typename F::T u = F::sub(F::mul(p.z, q.y), y1z2);
+    typename F::T v = F::sub(F::mul(p.z, q.x), x1z2);
+    if (F::is_zero(u) && F::is_zero(v)) return proj_dbl<C>(p);  // same point (swp.rs:586)
+    typename F::T uu = F::sqr(u);
+    typename F::T vv = F::sqr(v);
+    typename F::T vvv = F::mul(v, vv);
+    typename F::T r = F::mul(vv, x1z2);
+    typename F::T a = F::sub(F::sub(F::mul(uu, z1z2), vvv), F::dbl(r));
+    Proj<C> o;
+    o.x = F::mul(v, a);
+    o.y = F::sub(F::mul(F::sub(r, a), u), F::mul(vvv, y1z2));
+    o.z = F::mul(vvv, z1z2);
+    return o;
+}
+
+template <class C> GH_HD Aff<C> aff_neg(const Aff<C>& q) { return Aff<C>{q.x, C::F::neg(q.y)}; }
+
+}  // namespace gh

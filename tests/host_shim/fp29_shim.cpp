@@ -1,0 +1,72 @@
+// Host build (g++) of the device arithmetic headers, exported for ctypes so that
+// tests/test_fp29_host.py can check the exact code the HIP kernels run against Python integers.
+// Test infrastructure only; not part of the product library.
+#include <string.h>
+#include "../../ginger-lib_amd/csrc/ec29.h"
+
+using namespace gh;
+
+template <class P> static void fp_op(int op, const uint32_t* a, const uint32_t* b, uint32_t* out) {
+    Fp x = fp_unpack(a), y = fp_unpack(b), r;
+    switch (op) {
+        case 0: r = fp_mul<P>(x, y); break;
+        case 1: r = fp_sqr<P>(x); break;
+        case 2: r = fp_add<P>(x, y); break;
+        case 3: r = fp_sub<P>(x, y); break;
+        case 4: r = fp_neg<P>(x); break;
+        case 5: r = fp_dbl<P>(x); break;
+        case 6: r = fp_from_abi<P>(a); break;
+        case 7: fp_to_abi<P>(out, x); return;
+        case 8: r = fp_mul_small<P, 11>(x); break;
+        case 9: r = fp_mul_small<P, 13>(x); break;
+        case 10: r = fp_mul_small<P, 26>(x); break;
+        case 11: r = fp_mul_small<P, 121>(x); break;
+        default: r = fp_zero();
+    }
+    fp_pack(out, r);
+}
+
+// ABI layout for tower elements: DEG x 24 words, Montgomery radix 2^768.
+template <class C> static void ec_op(int op, const uint32_t* p, const uint32_t* q, uint32_t* out) {
+    typedef typename C::F F;
+    const int W = 24 * F::DEG;
+    Proj<C> a{F::from_abi(p), F::from_abi(p + W), F::from_abi(p + 2 * W)}, r;
+    switch (op) {
+        case 0: {  // madd: q affine (x, y)
+            Aff<C> b{F::from_abi(q), F::from_abi(q + W)};
+            r = proj_madd<C>(a, b);
+            break;
+        }
+        case 1: {
+            Proj<C> b{F::from_abi(q), F::from_abi(q + W), F::from_abi(q + 2 * W)};
+            r = proj_add<C>(a, b);
+            break;
+        }
+        case 2: r = proj_dbl<C>(a); break;
+        case 3: {  // field mul of the x coordinates (tower check)
+            r = a;
+            r.x = F::mul(a.x, F::from_abi(q));
+            break;
+        }
+        case 4: r = a; r.x = F::sqr(a.x); break;
+        default: r = proj_zero<C>();
+    }
+    F::to_abi(out, r.x);
+    F::to_abi(out + W, r.y);
+    F::to_abi(out + 2 * W, r.z);
+}
+
+extern "C" {
+void t_fp_op(int field, int op, const uint32_t* a, const uint32_t* b, uint32_t* out) {
+    if (field == 4) fp_op<P4>(op, a, b, out); else fp_op<P6>(op, a, b, out);
+}
+// curve: 0 mnt4753_g1, 1 mnt4753_g2, 2 mnt6753_g1, 3 mnt6753_g2
+void t_ec_op(int curve, int op, const uint32_t* p, const uint32_t* q, uint32_t* out) {
+    switch (curve) {
+        case 0: ec_op<Mnt4G1>(op, p, q, out); break;
+        case 1: ec_op<Mnt4G2>(op, p, q, out); break;
+        case 2: ec_op<Mnt6G1>(op, p, q, out); break;
+        case 3: ec_op<Mnt6G2>(op, p, q, out); break;
+    }
+}
+}

@@ -203,10 +203,24 @@ def main():
                       ("TWOINV_M", mont(pow(2, -1, p), F))):
             L.append("#define GH_%s_%s_64 %s" % (t, nm, arr64(v)))
             L.append("#define GH_%s_%s_32 %s" % (t, nm, arr32(v)))
+    # ---- device-internal representation: 26 limbs of 29 bits, Montgomery radix 2^754
+    def arr29(x):
+        assert 0 <= x < (1 << 754)
+        return "{" + ", ".join("0x%08xu" % ((x >> (29 * i)) & ((1 << 29) - 1)) for i in range(26)) + "}"
+    for F in (F4, F6):
+        t = F["tag"].upper()
+        p = F["p"]
+        L.append("// ---- field %s, device-internal radix-2^29 form (Montgomery radix 2^754)" % F["tag"])
+        L.append("#define GH_%s_INV29 0x%08xu" % (t, (-pow(p, -1, 1 << 29)) % (1 << 29)))
+        for nm, v in (("P29", p), ("ONE_I29", pow(2, 754, p)), ("CIN29", pow(2, 740, p)),
+                      ("COUT29", pow(2, 768, p)), ("R2I29", pow(2, 1508, p))):
+            L.append("#define GH_%s_%s %s" % (t, nm, arr29(v)))
     for nm, c in curves.items():
         F = F4 if c["field"] == "p4" else F6
         t = nm.upper()
         L.append("// ---- curve %s over %s^%d" % (nm, c["field"], c["ext"]))
+        for i, v in enumerate(c["a"]):
+            L.append("#define GH_%s_A%d_I29 %s" % (t, i, arr29((v * pow(2, 754, F["p"])) % F["p"])))
         L.append("#define GH_%s_EXT %d" % (t, c["ext"]))
         L.append("#define GH_%s_NONRESIDUE %d" % (t, c["nonresidue"]))
         for key in ("a", "b", "gx", "gy"):
