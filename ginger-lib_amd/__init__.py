@@ -1,0 +1,299 @@
+"""ginger-lib_amd -- Python binding of libginger_hip.so (the C ABI in include/ginger_hip.h).
+
+This is plumbing for tests, bench.py and the multi-GPU launcher: numpy arrays in the reference's
+in-memory formats go straight through ctypes to the HIP library.  The names mirror the reference's
+API for this path (algebra/src/msm/variable_base.rs:7-90, algebra/src/fft/domain.rs:24-179):
+
+    VariableBaseMSM.multi_scalar_mul(curve, bases, scalars, infinity=None) -> projective xyz
+    EvaluationDomain(field, num_coeffs).fft / ifft / coset_fft / coset_ifft (+ *_in_place)
+
+There is deliberately no fallback: if the shared library is missing or no gfx950 device is
+usable every call raises GingerHipError.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG_DIR, "libginger_hip.so")
+
+GH_OK = 0
+FFT_INVERSE = 1
+FFT_COSET = 2
+
+CURVES = {"mnt4753_g1": 0, "mnt4753_g2": 1, "mnt6753_g1": 2, "mnt6753_g2": 3}
+CURVE_DEG = {"mnt4753_g1": 1, "mnt4753_g2": 2, "mnt6753_g1": 1, "mnt6753_g2": 3}
+FIELDS = {"mnt4753_fr": 0, "mnt6753_fr": 1}
+
+# every symbol include/ginger_hip.h declares (checked by load_library and by tests/test_abi.py)
+ABI_SYMBOLS = [
+    "gh_init", "gh_shutdown", "gh_last_error", "gh_device_name",
+    "gh_msm", "gh_bases_upload", "gh_bases_free", "gh_bases_len", "gh_msm_resident", "gh_msm_resident_dev",
+    "gh_msm_set_window", "gh_msm_get_window", "gh_msm_last_timing",
+    "gh_domain_supported", "gh_fft", "gh_fft_dev", "gh_vec_mul_dev", "gh_vec_sub_dev", "gh_vec_scale_dev",
+    "gh_vec_mul", "gh_vec_scale", "gh_fft_last_kernel_ms",
+    "gh_dev_alloc", "gh_dev_free", "gh_dev_upload", "gh_dev_download", "gh_dev_sync",
+    "gh_proj_add", "gh_proj_to_affine",
+]
+
+
+class GingerHipError(RuntimeError):
+    pass
+
+
+class MsmTiming(ctypes.Structure):
+    _fields_ = [("sort_ms", ctypes.c_float), ("accumulate_ms", ctypes.c_float), ("reduce_ms", ctypes.c_float),
+                ("fold_ms", ctypes.c_float), ("total_ms", ctypes.c_float), ("window_bits", ctypes.c_int),
+                ("num_windows", ctypes.c_int), ("accumulate_madds", ctypes.c_ulonglong)]
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen the HIP library and bind every ABI symbol (no device is touched)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GingerHipError("HIP library not built: %s (run `python __graft_entry__.py`)" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    missing = [s for s in ABI_SYMBOLS if not hasattr(lib, s)]
+    if missing:
+        raise GingerHipError("libginger_hip.so lacks ABI symbols: %s" % missing)
+    vp, sz, u32, ci = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_int
+    lib.gh_last_error.restype = ctypes.c_char_p
+    lib.gh_device_name.restype = ctypes.c_char_p
+    lib.gh_init.argtypes = [vp, ci]
+    lib.gh_msm.argtypes = [ci, vp, vp, sz, vp, sz, vp]
+    lib.gh_bases_upload.argtypes = [ci, vp, vp, sz, ctypes.POINTER(vp)]
+    lib.gh_bases_free.argtypes = [vp]
+    lib.gh_bases_len.argtypes = [vp]
+    lib.gh_bases_len.restype = sz
+    lib.gh_msm_resident.argtypes = [vp, vp, sz, vp]
+    lib.gh_msm_resident_dev.argtypes = [vp, vp, sz, vp]
+    lib.gh_msm_set_window.argtypes = [ci]
+    lib.gh_msm_get_window.argtypes = [ci, sz]
+    lib.gh_msm_last_timing.argtypes = [ctypes.POINTER(MsmTiming)]
+    lib.gh_domain_supported.argtypes = [ci, sz, ctypes.POINTER(u32)]
+    lib.gh_fft.argtypes = [ci, vp, sz, vp, u32, u32]
+    lib.gh_fft_dev.argtypes = [ci, vp, u32, u32]
+    lib.gh_vec_mul_dev.argtypes = [ci, vp, vp, sz]
+    lib.gh_vec_sub_dev.argtypes = [ci, vp, vp, sz]
+    lib.gh_vec_scale_dev.argtypes = [ci, vp, vp, sz]
+    lib.gh_vec_mul.argtypes = [ci, vp, vp, sz]
+    lib.gh_vec_scale.argtypes = [ci, vp, vp, sz]
+    lib.gh_fft_last_kernel_ms.argtypes = [ctypes.POINTER(ctypes.c_float)]
+    lib.gh_dev_alloc.argtypes = [ctypes.POINTER(vp), sz]
+    lib.gh_dev_free.argtypes = [vp]
+    lib.gh_dev_upload.argtypes = [vp, vp, sz]
+    lib.gh_dev_download.argtypes = [vp, vp, sz]
+    lib.gh_proj_add.argtypes = [ci, vp, vp]
+    lib.gh_proj_to_affine.argtypes = [ci, vp, vp, vp]
+    _lib = lib
+    return lib
+
+
+def _check(rc):
+    if rc != GH_OK:
+        raise GingerHipError("ginger_hip error %d: %s" % (rc, load_library().gh_last_error().decode()))
+
+
+def _u64(a, words=None):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    if words is not None and a.size % words:
+        raise ValueError("array length is not a multiple of %d u64" % words)
+    return a
+
+
+def _ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p) if a is not None and a.size else None
+
+
+def init(device=None):
+    lib = load_library()
+    if device is None:
+        _check(lib.gh_init(None, 0))
+    else:
+        arr = (ctypes.c_int * 1)(int(device))
+        _check(lib.gh_init(arr, 1))
+
+
+def shutdown():
+    _check(load_library().gh_shutdown())
+
+
+def device_name():
+    return load_library().gh_device_name().decode()
+
+
+# ------------------------------------------------------------------------------ MSM
+class DeviceBuffer:
+    """Plain device allocation obtained through the C ABI (gh_dev_alloc)."""
+
+    def __init__(self, nbytes):
+        self.ptr = ctypes.c_void_p()
+        self.nbytes = int(nbytes)
+        _check(load_library().gh_dev_alloc(ctypes.byref(self.ptr), self.nbytes))
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= self.nbytes
+        _check(load_library().gh_dev_upload(self.ptr, _ptr(arr), arr.nbytes))
+        return self
+
+    def download(self, dtype=np.uint64):
+        out = np.empty(self.nbytes // np.dtype(dtype).itemsize, dtype=dtype)
+        _check(load_library().gh_dev_download(_ptr(out), self.ptr, out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            load_library().gh_dev_free(self.ptr)
+            self.ptr = ctypes.c_void_p()
+
+
+class ResidentBases:
+    """Device-resident MSM bases (the proving-key queries are static per circuit)."""
+
+    def __init__(self, curve, bases, infinity=None):
+        self.curve = curve
+        deg = CURVE_DEG[curve]
+        bases = _u64(bases, 24 * deg)
+        n = bases.size // (24 * deg)
+        inf = None
+        if infinity is not None:
+            inf = np.ascontiguousarray(infinity, dtype=np.uint8)
+            assert inf.size == n
+        self.handle = ctypes.c_void_p()
+        _check(load_library().gh_bases_upload(CURVES[curve], _ptr(bases), _ptr(inf) if inf is not None else None, n,
+                                               ctypes.byref(self.handle)))
+        self.n = n
+
+    def msm(self, scalars):
+        scalars = _u64(scalars, 12)
+        out = np.zeros(36 * CURVE_DEG[self.curve], dtype=np.uint64)
+        _check(load_library().gh_msm_resident(self.handle, _ptr(scalars), scalars.size // 12, _ptr(out)))
+        return out
+
+    def msm_dev(self, d_scalars, n_scalars):
+        out = np.zeros(36 * CURVE_DEG[self.curve], dtype=np.uint64)
+        _check(load_library().gh_msm_resident_dev(self.handle, d_scalars.ptr, n_scalars, _ptr(out)))
+        return out
+
+    def free(self):
+        if self.handle:
+            load_library().gh_bases_free(self.handle)
+            self.handle = ctypes.c_void_p()
+
+
+class VariableBaseMSM:
+    """Mirror of algebra::msm::VariableBaseMSM (variable_base.rs:7-90)."""
+
+    @staticmethod
+    def multi_scalar_mul(curve, bases, scalars, infinity=None):
+        """bases: n x 24*deg u64 (Montgomery x||y); scalars: m x 12 u64 canonical;
+        returns the projective sum as 36*deg u64 (X||Y||Z, Montgomery; Z == 0 <=> infinity)."""
+        deg = CURVE_DEG[curve]
+        bases = _u64(bases, 24 * deg)
+        scalars = _u64(scalars, 12)
+        n_b, n_s = bases.size // (24 * deg), scalars.size // 12
+        inf = None
+        if infinity is not None:
+            inf = np.ascontiguousarray(infinity, dtype=np.uint8)
+            assert inf.size == n_b
+        out = np.zeros(36 * deg, dtype=np.uint64)
+        _check(load_library().gh_msm(CURVES[curve], _ptr(bases), _ptr(inf) if inf is not None else None, n_b,
+                                      _ptr(scalars), n_s, _ptr(out)))
+        return out
+
+
+def msm_set_window(c):
+    _check(load_library().gh_msm_set_window(int(c)))
+
+
+def msm_last_timing():
+    t = MsmTiming()
+    _check(load_library().gh_msm_last_timing(ctypes.byref(t)))
+    return {k: getattr(t, k) for k, _ in MsmTiming._fields_}
+
+
+def proj_add(curve, acc, p):
+    acc = _u64(acc).copy()
+    p = _u64(p)
+    _check(load_library().gh_proj_add(CURVES[curve], _ptr(acc), _ptr(p)))
+    return acc
+
+
+def proj_to_affine(curve, xyz):
+    """-> (xy as 24*deg u64 Montgomery, is_infinity) : the reference's into_affine()."""
+    deg = CURVE_DEG[curve]
+    xyz = _u64(xyz)
+    out = np.zeros(24 * deg, dtype=np.uint64)
+    inf = np.zeros(1, dtype=np.uint8)
+    _check(load_library().gh_proj_to_affine(CURVES[curve], _ptr(xyz), _ptr(out), _ptr(inf)))
+    return out, bool(inf[0])
+
+
+# ------------------------------------------------------------------------------ FFT
+class EvaluationDomain:
+    """Mirror of algebra::fft::EvaluationDomain (domain.rs:24-179) for MNT4-753 Fr / MNT6-753 Fr.
+    `EvaluationDomain.new(field, n)` returns None where the reference's `new` does (domain.rs:69-71)."""
+
+    def __init__(self, field, num_coeffs):
+        lg = ctypes.c_uint32()
+        ok = load_library().gh_domain_supported(FIELDS[field], int(num_coeffs), ctypes.byref(lg))
+        if not ok:
+            raise GingerHipError("domain of 2^%d exceeds the 2-adicity of %s" % (lg.value, field))
+        self.field = field
+        self.log_size_of_group = lg.value
+        self.size = 1 << lg.value
+
+    @classmethod
+    def new(cls, field, num_coeffs):
+        try:
+            return cls(field, num_coeffs)
+        except GingerHipError:
+            return None
+
+    def _run(self, a, flags):
+        a = _u64(a, 12)
+        out = np.empty(self.size * 12, dtype=np.uint64)
+        _check(load_library().gh_fft(FIELDS[self.field], _ptr(a), a.size // 12, _ptr(out), self.log_size_of_group, flags))
+        return out
+
+    def fft(self, coeffs):
+        return self._run(coeffs, 0)
+
+    def ifft(self, evals):
+        return self._run(evals, FFT_INVERSE)
+
+    def coset_fft(self, coeffs):
+        return self._run(coeffs, FFT_COSET)
+
+    def coset_ifft(self, evals):
+        return self._run(evals, FFT_INVERSE | FFT_COSET)
+
+    def fft_dev(self, dbuf, flags=0):
+        _check(load_library().gh_fft_dev(FIELDS[self.field], dbuf.ptr, self.log_size_of_group, flags))
+
+    def mul_polynomials_in_evaluation_domain(self, a, b):
+        a = _u64(a, 12).copy()
+        b = _u64(b, 12)
+        assert a.size == b.size
+        _check(load_library().gh_vec_mul(FIELDS[self.field], _ptr(a), _ptr(b), a.size // 12))
+        return a
+
+
+def vec_scale(field, a, scalar12):
+    a = _u64(a, 12).copy()
+    s = _u64(scalar12, 12)
+    _check(load_library().gh_vec_scale(FIELDS[field], _ptr(a), _ptr(s), a.size // 12))
+    return a
+
+
+def fft_last_kernel_ms():
+    ms = ctypes.c_float()
+    _check(load_library().gh_fft_last_kernel_ms(ctypes.byref(ms)))
+    return ms.value

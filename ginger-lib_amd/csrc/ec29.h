@@ -12,20 +12,26 @@
 namespace gh {
 
 // ----- curve policies: base-field tower + multiplication by the curve coefficient a
+// F  = field policy with the Fp product inlined (G1 accumulation inner loop);
+// FC = the same field with out-of-line products, used by the proj_*_call instances below.
 struct Mnt4G1 {  // y^2 = x^3 + 2x + b over p4       (curves/mnt4753/g1.rs:19-50)
-    typedef F1<P4> F;
+    typedef F1<P4, true> F;
+    typedef F1<P4, false> FC;
     static GH_HD F::T mul_by_a(const F::T& z) { return fp_dbl<P4>(z); }
 };
 struct Mnt6G1 {  // y^2 = x^3 + 11x + b over p6      (curves/mnt6753/g1.rs:19-52)
-    typedef F1<P6> F;
+    typedef F1<P6, true> F;
+    typedef F1<P6, false> FC;
     static GH_HD F::T mul_by_a(const F::T& z) { return fp_mul_small<P6, 11>(z); }
 };
 struct Mnt4G2 {  // twist over Fq2, a' = (26, 0)     (curves/mnt4753/g2.rs:57-75, mul_by_a :113-118)
     typedef F2<P4, 13> F;
+    typedef F2<P4, 13> FC;
     static GH_HD F::T mul_by_a(const F::T& z) { return F::T{fp_mul_small<P4, 26>(z.c0), fp_mul_small<P4, 26>(z.c1)}; }
 };
 struct Mnt6G2 {  // twist over Fq3, a' = (0, 0, 11)  (curves/mnt6753/g2.rs:71-100, mul_by_a :149-155)
     typedef F3<P6, 11> F;
+    typedef F3<P6, 11> FC;
     static GH_HD F::T mul_by_a(const F::T& z) {
         return F::T{fp_mul_small<P6, 121>(z.c1), fp_mul_small<P6, 121>(z.c2), fp_mul_small<P6, 11>(z.c0)};
     }
@@ -44,8 +50,7 @@ template <class C> GH_HD Proj<C> proj_zero() {  // (0, 1, 0)   swp.rs:372-378
 }
 template <class C> GH_HD bool proj_is_zero(const Proj<C>& p) { return C::F::is_zero(p.z); }
 
-template <class C> GH_HD Proj<C> proj_dbl(const Proj<C>& p) {
-    typedef typename C::F F;
+template <class C, class F = typename C::F> GH_HD Proj<C> proj_dbl(const Proj<C>& p) {
     if (proj_is_zero(p)) return p;
     typename F::T xx = F::sqr(p.x);
     typename F::T zz = F::sqr(p.z);
@@ -63,13 +68,14 @@ template <class C> GH_HD Proj<C> proj_dbl(const Proj<C>& p) {
     return o;
 }
 
+template <class C> GH_HD_NOINLINE Proj<C> proj_dbl_call(const Proj<C>& p);
+
 // p += q, q affine and NOT the point at infinity (callers drop infinity bases: swp.rs:482-483)
-template <class C> GH_HD Proj<C> proj_madd(const Proj<C>& p, const Aff<C>& q) {
-    typedef typename C::F F;
+template <class C, class F = typename C::F> GH_HD Proj<C> proj_madd(const Proj<C>& p, const Aff<C>& q) {
     if (proj_is_zero(p)) return Proj<C>{q.x, q.y, F::one()};
     typename F::T v = F::mul(q.x, p.z);
     typename F::T u = F::mul(q.y, p.z);
-    if (F::eq(u, p.y) && F::eq(v, p.x)) return proj_dbl<C>(p);
+    if (F::eq(u, p.y) && F::eq(v, p.x)) return proj_dbl_call<C>(p);
     u = F::sub(u, p.y);
     typename F::T uu = F::sqr(u);
     v = F::sub(v, p.x);
@@ -84,8 +90,7 @@ template <class C> GH_HD Proj<C> proj_madd(const Proj<C>& p, const Aff<C>& q) {
     return o;
 }
 
-template <class C> GH_HD Proj<C> proj_add(const Proj<C>& p, const Proj<C>& q) {
-    typedef typename C::F F;
+template <class C, class F = typename C::F> GH_HD Proj<C> proj_add(const Proj<C>& p, const Proj<C>& q) {
     if (proj_is_zero(p)) return q;
     if (proj_is_zero(q)) return p;
     typename F::T y1z2 = F::mul(p.y, q.z);
@@ -93,7 +98,7 @@ template <class C> GH_HD Proj<C> proj_add(const Proj<C>& p, const Proj<C>& q) {
     typename F::T z1z2 = F::mul(p.z, q.z);
     typename F::T u = F::sub(F::mul(p.z, q.y), y1z2);
     typename F::T v = F::sub(F::mul(p.z, q.x), x1z2);
-    if (F::is_zero(u) && F::is_zero(v)) return proj_dbl<C>(p);  // same point (swp.rs:586)
+    if (F::is_zero(u) && F::is_zero(v)) return proj_dbl_call<C>(p);  // same point (swp.rs:586)
     typename F::T uu = F::sqr(u);
     typename F::T vv = F::sqr(v);
     typename F::T vvv = F::mul(v, vv);
@@ -105,6 +110,16 @@ template <class C> GH_HD Proj<C> proj_add(const Proj<C>& p, const Proj<C>& q) {
     o.z = F::mul(vvv, z1z2);
     return o;
 }
+
+// Out-of-line instances for everything that is not the accumulation inner loop.  They are built
+// on the out-of-line Fp product (FC), which keeps each of them a few KB.  This is not only about
+// code size: hipcc (ROCm 7.2) relaxes a branch that spans more than 2^15 dwords into
+// s_getpc_b64 s[30:31] / s_setpc_b64 and in a LEAF function s[30:31] still holds the return
+// address, so a 140 KB leaf proj_dbl with an early `return p` never returned (it looped on its
+// own epilogue).  Small callees have no long branches.
+template <class C> GH_HD_NOINLINE Proj<C> proj_dbl_call(const Proj<C>& p) { return proj_dbl<C, typename C::FC>(p); }
+template <class C> GH_HD_NOINLINE Proj<C> proj_add_call(const Proj<C>& p, const Proj<C>& q) { return proj_add<C, typename C::FC>(p, q); }
+template <class C> GH_HD_NOINLINE Proj<C> proj_madd_call(const Proj<C>& p, const Aff<C>& q) { return proj_madd<C, typename C::FC>(p, q); }
 
 template <class C> GH_HD Aff<C> aff_neg(const Aff<C>& q) { return Aff<C>{q.x, C::F::neg(q.y)}; }
 

@@ -1,0 +1,370 @@
+// ginger_hip.hip -- the C ABI declared in include/ginger_hip.h plus the process-wide runtime
+// (device context, workspace pool, prefix scan).  Per-curve MSM code lives in msm_<curve>.hip,
+// the transforms in ntt.hip.  Build: __graft_entry__.py build() (hipcc --offload-arch=gfx950).
+#include <stdlib.h>
+#include <string.h>
+#include "runtime.h"
+#include "scan_kernels.h"
+
+namespace gh_rt {
+
+Ctx g;
+std::string g_err;
+static std::mutex g_mu;
+static char g_devname[256] = "";
+
+int ensure_init() {
+    if (g.ready) return GH_OK;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0) {
+        g_err = "no HIP device visible (this library has no CPU fallback)";
+        return GH_E_NO_DEVICE;
+    }
+    int dev = 0;
+    const char* lr = getenv("LOCAL_RANK");
+    if (lr) dev = atoi(lr) % count;
+    g.device = dev;
+    HIPCHK(hipSetDevice(dev));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, dev));
+    snprintf(g_devname, sizeof g_devname, "%s, %d CUs, %s", prop.name, prop.multiProcessorCount, prop.gcnArchName);
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        g_err = std::string("device is not gfx950: ") + prop.gcnArchName;
+        return GH_E_NO_DEVICE;
+    }
+    HIPCHK(hipStreamCreate(&g.stream));
+    for (auto& ev : g.ev) HIPCHK(hipEventCreate(&ev));
+    g.ready = true;
+    return GH_OK;
+}
+
+int pool_get(const char* name, size_t bytes, void** out) {
+    DevBuf& b = g.pool[name];
+    if (b.cap < bytes) {
+        if (b.p) { HIPCHK(hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+        size_t cap = bytes + bytes / 8 + 256;
+        HIPCHK(hipMalloc(&b.p, cap));
+        b.cap = cap;
+    }
+    *out = b.p;
+    return GH_OK;
+}
+
+// generic exclusive scan of n u32 on the library stream
+int device_scan(const uint32_t* in, uint32_t* out, size_t n, const char* tmpname) {
+    using namespace gh;
+    size_t per_block = (size_t)SCAN_BLOCK * SCAN_ITEMS;
+    size_t nblocks = (n + per_block - 1) / per_block;
+    uint32_t* sums;
+    int rc = pool_get(tmpname, (nblocks + 1) * 4, (void**)&sums);
+    if (rc) return rc;
+    hipLaunchKernelGGL(scan_partials_kernel, dim3((unsigned)nblocks), dim3(SCAN_BLOCK), 0, g.stream, in, sums, n);
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, g.stream, sums, nblocks);
+    hipLaunchKernelGGL(scan_final_kernel, dim3((unsigned)nblocks), dim3(SCAN_BLOCK), 0, g.stream, in, sums, out, n);
+    HIPCHK(hipGetLastError());
+    return GH_OK;
+}
+
+int auto_window(size_t n) {
+    if (g.window_override > 0) return g.window_override;
+    int lg = 0;
+    while (((size_t)1 << (lg + 1)) <= n) lg++;
+    int c = lg - 4;
+    if (c < 4) c = 4;
+    if (c > 20) c = 20;
+    return c;
+}
+
+static const MsmOps* ops_of(gh_curve_t curve) {
+    switch (curve) {
+        case GH_MNT4753_G1: return msm_ops_mnt4753_g1();
+        case GH_MNT4753_G2: return msm_ops_mnt4753_g2();
+        case GH_MNT6753_G1: return msm_ops_mnt6753_g1();
+        case GH_MNT6753_G2: return msm_ops_mnt6753_g2();
+        default: g_err = "unknown curve id"; return nullptr;
+    }
+}
+
+}  // namespace gh_rt
+
+using namespace gh_rt;
+
+// ==========================================================================================
+extern "C" {
+
+int gh_init(const int* devices, int n_devices) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g.ready) return GH_OK;
+    if (devices && n_devices > 0) {
+        int count = 0;
+        if (hipGetDeviceCount(&count) != hipSuccess || count == 0) { g_err = "no HIP device visible"; return GH_E_NO_DEVICE; }
+        if (devices[0] < 0 || devices[0] >= count) { g_err = "device index out of range"; return GH_E_BAD_ARG; }
+        char b[16]; snprintf(b, sizeof b, "%d", devices[0]);
+        setenv("LOCAL_RANK", b, 1);
+    }
+    return ensure_init();
+}
+
+int gh_shutdown(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g.ready) return GH_OK;
+    hipStreamSynchronize(g.stream);
+    for (auto& kv : g.pool) if (kv.second.p) hipFree(kv.second.p);
+    g.pool.clear();
+    for (int f = 0; f < 2; f++) {
+        for (auto& kv : g.domains[f]) {
+            Domain& d = kv.second;
+            if (d.tw) hipFree(d.tw);
+            if (d.coset) hipFree(d.coset);
+            if (d.coset_inv) hipFree(d.coset_inv);
+            if (d.scratch) hipFree(d.scratch);
+        }
+        g.domains[f].clear();
+    }
+    for (auto& ev : g.ev) hipEventDestroy(ev);
+    hipStreamDestroy(g.stream);
+    g.ready = false;
+    return GH_OK;
+}
+
+const char* gh_last_error(void) { return g_err.c_str(); }
+const char* gh_device_name(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (ensure_init()) return "";
+    return g_devname;
+}
+
+int gh_msm(gh_curve_t curve, const uint64_t* bases, const uint8_t* infinity, size_t n_bases, const uint64_t* scalars,
+           size_t n_scalars, uint64_t* out_xyz) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!out_xyz || (n_bases && !bases) || (n_scalars && !scalars)) { g_err = "null argument"; return GH_E_BAD_ARG; }
+    const MsmOps* ops = ops_of(curve);
+    if (!ops) return GH_E_BAD_ARG;
+    int rc = ensure_init();
+    if (rc) return rc;
+    return ops->host(bases, infinity, n_bases, scalars, n_scalars, out_xyz);
+}
+
+int gh_bases_upload(gh_curve_t curve, const uint64_t* bases, const uint8_t* infinity, size_t n_bases, gh_bases_t* out_handle) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!out_handle || (n_bases && !bases)) { g_err = "null argument"; return GH_E_BAD_ARG; }
+    const MsmOps* ops = ops_of(curve);
+    if (!ops) return GH_E_BAD_ARG;
+    int rc = ensure_init();
+    if (rc) return rc;
+    BasesBase* h = nullptr;
+    rc = ops->upload(bases, infinity, n_bases, &h);
+    if (rc) return rc;
+    *out_handle = reinterpret_cast<gh_bases_t>(h);
+    return GH_OK;
+}
+
+int gh_bases_free(gh_bases_t handle) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    BasesBase* h = reinterpret_cast<BasesBase*>(handle);
+    if (!h || h->magic != 0x6768424au) { g_err = "bad bases handle"; return GH_E_BAD_HANDLE; }
+    if (h->d_points) hipFree(h->d_points);
+    if (h->d_inf) hipFree(h->d_inf);
+    h->magic = 0;
+    delete h;
+    return GH_OK;
+}
+
+size_t gh_bases_len(gh_bases_t handle) {
+    BasesBase* h = reinterpret_cast<BasesBase*>(handle);
+    return (h && h->magic == 0x6768424au) ? h->n : 0;
+}
+
+int gh_msm_resident_dev(gh_bases_t handle, const void* d_scalars, size_t n_scalars, uint64_t* out_xyz) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    BasesBase* h = reinterpret_cast<BasesBase*>(handle);
+    if (!h || h->magic != 0x6768424au) { g_err = "bad bases handle"; return GH_E_BAD_HANDLE; }
+    if (!out_xyz || (n_scalars && !d_scalars)) { g_err = "null argument"; return GH_E_BAD_ARG; }
+    const MsmOps* ops = ops_of(h->curve);
+    if (!ops) return GH_E_BAD_ARG;
+    int rc = ensure_init();
+    if (rc) return rc;
+    return ops->run(h, d_scalars, n_scalars, out_xyz);
+}
+
+int gh_msm_resident(gh_bases_t handle, const uint64_t* scalars, size_t n_scalars, uint64_t* out_xyz) {
+    void* d_s = nullptr;
+    size_t n = 0;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        BasesBase* h = reinterpret_cast<BasesBase*>(handle);
+        if (!h || h->magic != 0x6768424au) { g_err = "bad bases handle"; return GH_E_BAD_HANDLE; }
+        if (!out_xyz || (n_scalars && !scalars)) { g_err = "null argument"; return GH_E_BAD_ARG; }
+        int rc = ensure_init();
+        if (rc) return rc;
+        n = h->n < n_scalars ? h->n : n_scalars;
+        if (n > 0) {
+            rc = pool_get("scalars", n * 96, &d_s);
+            if (rc) return rc;
+            HIPCHK(hipMemcpyAsync(d_s, scalars, n * 96, hipMemcpyHostToDevice, g.stream));
+        }
+    }
+    return gh_msm_resident_dev(handle, n ? d_s : (const void*)scalars, n, out_xyz);
+}
+
+int gh_msm_set_window(int c) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (c < 0 || c > 24 || c == 1) { g_err = "window must be 0 (auto) or in [2, 24]"; return GH_E_BAD_ARG; }
+    g.window_override = c;
+    return GH_OK;
+}
+int gh_msm_get_window(gh_curve_t, size_t n) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    return auto_window(n);
+}
+int gh_msm_last_timing(gh_msm_timing_t* out) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (out) *out = g.last_msm;
+    return GH_OK;
+}
+
+int gh_domain_supported(gh_field_t field, size_t num_coeffs, uint32_t* log_n) {
+    size_t size = 1;
+    uint32_t lg = 0;
+    while (size < num_coeffs) { size <<= 1; lg++; }
+    if (log_n) *log_n = lg;
+    int two_adicity = field == GH_MNT4753_FR ? GH_P6_TWO_ADICITY : GH_P4_TWO_ADICITY;
+    return (int)lg < two_adicity ? 1 : 0;
+}
+
+int gh_fft_dev(gh_field_t field, void* d_data, uint32_t log_n, uint32_t flags) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!d_data) { g_err = "null argument"; return GH_E_BAD_ARG; }
+    int rc = ensure_init();
+    if (rc) return rc;
+    return fft_run(field, d_data, log_n, flags);
+}
+
+int gh_fft(gh_field_t field, const uint64_t* in, size_t n_in, uint64_t* out, uint32_t log_n, uint32_t flags) {
+    if (!out || (n_in && !in)) { g_err = "null argument"; return GH_E_BAD_ARG; }
+    if (log_n >= 31) { g_err = "domain too large"; return GH_E_UNSUPPORTED; }
+    const size_t N = (size_t)1 << log_n;
+    void* d = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        int rc = ensure_init();
+        if (rc) return rc;
+        int two_adicity = field == GH_MNT4753_FR ? GH_P6_TWO_ADICITY : GH_P4_TWO_ADICITY;
+        if ((int)log_n >= two_adicity) { g_err = "domain exceeds the field's 2-adicity"; return GH_E_UNSUPPORTED; }
+        rc = pool_get("fft_io", N * 96, &d);
+        if (rc) return rc;
+        size_t ncopy = n_in < N ? n_in : N;  // Vec::resize: truncate or zero-pad (domain.rs:121)
+        if (ncopy) HIPCHK(hipMemcpyAsync(d, in, ncopy * 96, hipMemcpyHostToDevice, g.stream));
+        if (ncopy < N) HIPCHK(hipMemsetAsync((char*)d + ncopy * 96, 0, (N - ncopy) * 96, g.stream));
+    }
+    int rc = gh_fft_dev(field, d, log_n, flags);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(g_mu);
+    HIPCHK(hipMemcpyAsync(out, d, N * 96, hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    return GH_OK;
+}
+
+int gh_fft_last_kernel_ms(float* ms) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (ms) *ms = g.last_fft_ms;
+    return GH_OK;
+}
+
+static int vec_dispatch(gh_field_t field, int op, void* d_a, const void* d_b, const uint64_t* s, size_t n) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!d_a || (op != 2 && !d_b) || (op == 2 && !s)) { g_err = "null argument"; return GH_E_BAD_ARG; }
+    int rc = ensure_init();
+    if (rc) return rc;
+    return vec_op(field, op, d_a, d_b, s, n);
+}
+int gh_vec_mul_dev(gh_field_t field, void* d_a, const void* d_b, size_t n) { return vec_dispatch(field, 0, d_a, d_b, nullptr, n); }
+int gh_vec_sub_dev(gh_field_t field, void* d_a, const void* d_b, size_t n) { return vec_dispatch(field, 1, d_a, d_b, nullptr, n); }
+int gh_vec_scale_dev(gh_field_t field, void* d_a, const uint64_t* scalar12, size_t n) { return vec_dispatch(field, 2, d_a, nullptr, scalar12, n); }
+
+int gh_vec_mul(gh_field_t field, uint64_t* a, const uint64_t* b, size_t n) {
+    if (n == 0) return GH_OK;
+    if (!a || !b) { g_err = "null argument"; return GH_E_BAD_ARG; }
+    void *da = nullptr, *db = nullptr;
+    int rc;
+    if ((rc = gh_dev_alloc(&da, n * 96))) return rc;
+    if ((rc = gh_dev_alloc(&db, n * 96))) { gh_dev_free(da); return rc; }
+    rc = gh_dev_upload(da, a, n * 96);
+    if (!rc) rc = gh_dev_upload(db, b, n * 96);
+    if (!rc) rc = gh_vec_mul_dev(field, da, db, n);
+    if (!rc) rc = gh_dev_download(a, da, n * 96);
+    gh_dev_free(da);
+    gh_dev_free(db);
+    return rc;
+}
+int gh_vec_scale(gh_field_t field, uint64_t* a, const uint64_t* scalar12, size_t n) {
+    if (n == 0) return GH_OK;
+    if (!a || !scalar12) { g_err = "null argument"; return GH_E_BAD_ARG; }
+    void* da = nullptr;
+    int rc;
+    if ((rc = gh_dev_alloc(&da, n * 96))) return rc;
+    rc = gh_dev_upload(da, a, n * 96);
+    if (!rc) rc = gh_vec_scale_dev(field, da, scalar12, n);
+    if (!rc) rc = gh_dev_download(a, da, n * 96);
+    gh_dev_free(da);
+    return rc;
+}
+
+int gh_dev_alloc(void** d_ptr, size_t bytes) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!d_ptr) { g_err = "null argument"; return GH_E_BAD_ARG; }
+    int rc = ensure_init();
+    if (rc) return rc;
+    HIPCHK(hipMalloc(d_ptr, bytes ? bytes : 1));
+    return GH_OK;
+}
+int gh_dev_free(void* d_ptr) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!d_ptr) return GH_OK;
+    HIPCHK(hipFree(d_ptr));
+    return GH_OK;
+}
+int gh_dev_upload(void* d_dst, const void* h_src, size_t bytes) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!bytes) return GH_OK;
+    if (!d_dst || !h_src) { g_err = "null argument"; return GH_E_BAD_ARG; }
+    int rc = ensure_init();
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    return GH_OK;
+}
+int gh_dev_download(void* h_dst, const void* d_src, size_t bytes) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!bytes) return GH_OK;
+    if (!h_dst || !d_src) { g_err = "null argument"; return GH_E_BAD_ARG; }
+    int rc = ensure_init();
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    return GH_OK;
+}
+int gh_dev_sync(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    int rc = ensure_init();
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(g.stream));
+    return GH_OK;
+}
+
+int gh_proj_add(gh_curve_t curve, uint64_t* acc_xyz, const uint64_t* p_xyz) {
+    if (!acc_xyz || !p_xyz) { g_err = "null argument"; return GH_E_BAD_ARG; }
+    const MsmOps* ops = ops_of(curve);
+    if (!ops) return GH_E_BAD_ARG;
+    return ops->proj_add(acc_xyz, p_xyz);
+}
+
+int gh_proj_to_affine(gh_curve_t curve, const uint64_t* xyz, uint64_t* out_xy, uint8_t* is_infinity) {
+    if (!xyz || !out_xy || !is_infinity) { g_err = "null argument"; return GH_E_BAD_ARG; }
+    const MsmOps* ops = ops_of(curve);
+    if (!ops) return GH_E_BAD_ARG;
+    return ops->to_affine(xyz, out_xy, is_infinity);
+}
+
+}  // extern "C"

@@ -1,0 +1,314 @@
+// msm_kernels.h -- variable-base multi-scalar multiplication (Pippenger bucket method) on gfx950.
+//
+// Reference algorithm: algebra/src/msm/variable_base.rs:10-83 -- per c-bit window a *serial* loop
+// over all pairs doing buckets[digit-1].add_assign_mixed(base) (:36-59), batch-normalise, running
+// sum (:60-66), then a Horner fold of the windows (:73-82); parallelism = number of windows.
+// The group sum is order-independent (only the affine image of the result is canonical),
+// so the device uses its own schedule:
+//
+//   1. msm_digits_kernel     one thread per scalar: signed c-bit digits d in [-2^(c-1), 2^(c-1)]
+//                            (halves the bucket count), histogram of |d| per (window, bucket).
+//   2. exclusive scan of the histogram (msm_scan_*), bucket order by descending size
+//      (msm_size_*: counting sort on the bucket size so the 64 lanes of a wave get equal work).
+//   3. msm_scatter_kernel    counting-sort scatter: for every bucket the list of (pair index | sign).
+//   4. msm_accumulate_kernel one thread per bucket walks its list: gather the base (internal
+//                            layout, 208 B for G1), conditional negate, projective mixed add
+//                            (ec29.h proj_madd, 11 Fp-mul).  ~94 % of all work (as in the reference).
+//      msm_heavy_kernel      buckets longer than HEAVY_THRESHOLD are split over the lanes of a
+//                            wave and tree-reduced through LDS (skewed real-world witnesses: many
+//                            equal small scalars land in one bucket).
+//   5. msm_reduce1/2_kernel  sum_b b * B_b per window without the reference's per-window inversion:
+//                            each lane serially folds L consecutive buckets (running sum), then the
+//                            64 lanes of the wave combine their (run, weighted) pairs with a
+//                            log-step suffix scan + tree reduction through LDS ("wavefront-wide
+//                            bucket reduction"); a second launch combines the waves of a window.
+//   6. window fold           753 dependent doublings: latency-bound, done on the host
+//                            (ginger_hip.hip: fold_windows_host) from the W window sums.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "ec29.h"
+
+namespace gh {
+
+constexpr int MSM_REDUCE_L = 8;          // buckets folded serially per lane in reduce level 1
+constexpr int MSM_HEAVY_THRESHOLD = 1024;  // bucket sizes above this go to the wave-cooperative path
+constexpr int MSM_SIZE_BINS = MSM_HEAVY_THRESHOLD + 2;
+
+// ---------------------------------------------------------------- generic point load / store
+template <class C> __device__ __forceinline__ Aff<C> ld_aff(const Aff<C>* p) {
+    Aff<C> r;
+    const uint2* q = reinterpret_cast<const uint2*>(p);
+    uint2* d = reinterpret_cast<uint2*>(&r);
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(Aff<C>) / 8); i++) d[i] = q[i];
+    return r;
+}
+template <class C> __device__ __forceinline__ Proj<C> ld_proj(const Proj<C>* p) {
+    Proj<C> r;
+    const uint2* q = reinterpret_cast<const uint2*>(p);
+    uint2* d = reinterpret_cast<uint2*>(&r);
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(Proj<C>) / 8); i++) d[i] = q[i];
+    return r;
+}
+template <class C> __device__ __forceinline__ void st_proj(Proj<C>* p, const Proj<C>& v) {
+    uint2* q = reinterpret_cast<uint2*>(p);
+    const uint2* s = reinterpret_cast<const uint2*>(&v);
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(Proj<C>) / 8); i++) q[i] = s[i];
+}
+
+// ---------------------------------------------------------------- bases: ABI -> internal layout
+// in: n x (2 * DEG * 24) words (x || y, Montgomery 2^768); out: n x Aff<C> (internal 2^754)
+template <class C>
+__global__ void __launch_bounds__(256) msm_convert_bases_kernel(const uint32_t* in, Aff<C>* out, size_t n) {
+    typedef typename C::F F;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t* p = in + i * (size_t)(48 * F::DEG);
+    Aff<C> a;
+    a.x = F::from_abi(p);
+    a.y = F::from_abi(p + 24 * F::DEG);
+    uint2* q = reinterpret_cast<uint2*>(out + i);
+    const uint2* s = reinterpret_cast<const uint2*>(&a);
+#pragma unroll
+    for (int w = 0; w < (int)(sizeof(Aff<C>) / 8); w++) q[w] = s[w];
+}
+
+// ---------------------------------------------------------------- 1. digits + histogram
+// scalars: n x 24 words canonical.  digits[w * n + i] = signed digit (0 = no contribution).
+// counts[w * nb + |d|] += 1, nb = 2^(c-1) + 1 (slot 0 unused).
+// Signed recoding: v = bits(s, wc, c) + carry; if v > 2^(c-1): d = v - 2^c, carry = 1.
+// num_windows = floor(753 / c) + 1 guarantees the top window never carries out.
+// (reference digit rule, unsigned: variable_base.rs:43-50.)
+static __global__ void __launch_bounds__(256)
+msm_digits_kernel(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ infinity, size_t n, int c,
+                  int num_windows, uint32_t nb, int32_t* __restrict__ digits, uint32_t* __restrict__ counts) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t s[25];
+    const uint4* q = reinterpret_cast<const uint4*>(scalars + i * 24);
+#pragma unroll
+    for (int k = 0; k < 6; k++) { uint4 v = q[k]; s[4 * k] = v.x; s[4 * k + 1] = v.y; s[4 * k + 2] = v.z; s[4 * k + 3] = v.w; }
+    s[24] = 0;
+    const bool skip = infinity != nullptr && infinity[i] != 0;
+    const uint32_t half = 1u << (c - 1), full_mask = (c == 32) ? 0xFFFFFFFFu : ((1u << c) - 1);
+    uint32_t carry = 0;
+    for (int w = 0; w < num_windows; w++) {
+        const int bit = w * c;
+        uint32_t v = 0;
+        if (bit < 768) {
+            const int wi = bit >> 5, sh = bit & 31;
+            uint64_t two = (uint64_t)s[wi] | ((uint64_t)s[wi + 1] << 32);
+            v = (uint32_t)(two >> sh) & full_mask;
+        }
+        v += carry;
+        int32_t d;
+        if (v > half) { d = (int32_t)v - (int32_t)(1u << c); carry = 1; } else { d = (int32_t)v; carry = 0; }
+        if (skip) d = 0;
+        digits[(size_t)w * n + i] = d;
+        if (d != 0) {
+            uint32_t mag = d < 0 ? (uint32_t)(-d) : (uint32_t)d;
+            atomicAdd(&counts[(size_t)w * nb + mag], 1u);
+        }
+    }
+}
+
+// ---------------------------------------------------------------- 2b. bucket order by descending size
+// size bin = min(count, HEAVY_THRESHOLD + 1); bins are laid out so that larger sizes come first.
+static __global__ void __launch_bounds__(256) msm_size_hist_kernel(const uint32_t* counts, size_t total, uint32_t* size_hist) {
+    size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    uint32_t cnt = counts[g];
+    uint32_t bin = cnt > (uint32_t)MSM_HEAVY_THRESHOLD ? (uint32_t)MSM_HEAVY_THRESHOLD + 1 : cnt;
+    atomicAdd(&size_hist[MSM_SIZE_BINS - 1 - bin], 1u);  // reversed: big first
+}
+static __global__ void __launch_bounds__(256) msm_size_scatter_kernel(const uint32_t* counts, size_t total, uint32_t* size_cursor, uint32_t* order) {
+    size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    uint32_t cnt = counts[g];
+    uint32_t bin = cnt > (uint32_t)MSM_HEAVY_THRESHOLD ? (uint32_t)MSM_HEAVY_THRESHOLD + 1 : cnt;
+    uint32_t pos = atomicAdd(&size_cursor[MSM_SIZE_BINS - 1 - bin], 1u);
+    order[pos] = (uint32_t)g;
+}
+
+// ---------------------------------------------------------------- 3. scatter
+static __global__ void __launch_bounds__(256)
+msm_scatter_kernel(const int32_t* __restrict__ digits, size_t n, int num_windows, uint32_t nb,
+                   uint32_t* __restrict__ cursor /* = copy of starts */, uint32_t* __restrict__ sorted) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int w = blockIdx.y;
+    if (i >= n) return;
+    int32_t d = digits[(size_t)w * n + i];
+    if (d == 0) return;
+    uint32_t mag = d < 0 ? (uint32_t)(-d) : (uint32_t)d;
+    uint32_t pos = atomicAdd(&cursor[(size_t)w * nb + mag], 1u);
+    sorted[pos] = (uint32_t)i | (d < 0 ? 0x80000000u : 0u);
+}
+
+// ---------------------------------------------------------------- 4. bucket accumulation
+// order[] lists bucket ids by descending size: [0, n_heavy) are heavy (handled by msm_heavy_kernel),
+// the rest is walked here one bucket per thread; empty buckets store infinity.
+template <class C>
+__global__ void __launch_bounds__(256)
+msm_accumulate_kernel(const Aff<C>* __restrict__ bases, const uint32_t* __restrict__ sorted,
+                      const uint32_t* __restrict__ starts, const uint32_t* __restrict__ counts,
+                      const uint32_t* __restrict__ order, uint32_t first, uint32_t total, Proj<C>* __restrict__ buckets) {
+    typedef typename C::F F;
+    uint32_t t = first + blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const uint32_t g = order[t];
+    const uint32_t beg = starts[g], cnt = counts[g];
+    Proj<C> acc = proj_zero<C>();
+    for (uint32_t k = 0; k < cnt; k++) {
+        const uint32_t e = sorted[beg + k];
+        Aff<C> q = ld_aff<C>(bases + (e & 0x7FFFFFFFu));
+        if (e >> 31) q.y = F::neg(q.y);
+        acc = proj_madd<C>(acc, q);
+    }
+    st_proj<C>(buckets + g, acc);
+}
+
+// wave-level sum of one projective point per lane through LDS; result valid in lane 0.
+// sh must hold 64 Proj<C>.  All 64 lanes must call.
+template <class C>
+__device__ __forceinline__ Proj<C> wave_tree_sum(Proj<C> v, Proj<C>* sh, int lane) {
+    for (int off = 32; off > 0; off >>= 1) {
+        if (lane >= off && lane < 2 * off) st_proj<C>(sh + lane, v);
+        __syncthreads();
+        if (lane < off) v = proj_add_call<C>(v, ld_proj<C>(sh + lane + off));
+        __syncthreads();
+    }
+    return v;
+}
+
+// one wave (block of 64) per heavy bucket
+template <class C>
+__global__ void __launch_bounds__(64)
+msm_heavy_kernel(const Aff<C>* __restrict__ bases, const uint32_t* __restrict__ sorted,
+                 const uint32_t* __restrict__ starts, const uint32_t* __restrict__ counts,
+                 const uint32_t* __restrict__ order, Proj<C>* __restrict__ buckets) {
+    typedef typename C::F F;
+    extern __shared__ uint32_t lds_raw[];
+    Proj<C>* sh = reinterpret_cast<Proj<C>*>(lds_raw);
+    const uint32_t g = order[blockIdx.x];
+    const uint32_t beg = starts[g], cnt = counts[g];
+    const int lane = threadIdx.x;
+    Proj<C> acc = proj_zero<C>();
+    for (uint32_t k = lane; k < cnt; k += 64) {
+        const uint32_t e = sorted[beg + k];
+        Aff<C> q = ld_aff<C>(bases + (e & 0x7FFFFFFFu));
+        if (e >> 31) q.y = F::neg(q.y);
+        acc = proj_madd_call<C>(acc, q);
+    }
+    acc = wave_tree_sum<C>(acc, sh, lane);
+    if (lane == 0) st_proj<C>(buckets + g, acc);
+}
+
+// ---------------------------------------------------------------- 5. bucket reduction
+// Level 1: block = one wave, covers 64 * L consecutive bucket slots of ONE window
+// (slots per window nbp = padded to a multiple of 64 * L; slot index == bucket weight).
+// Lane l folds slots [l L, l L + L): run = sum B, wacc = sum (i) B_(lL + i)  (local weights 0..L-1).
+// Wave combine: S_l = suffix sum of run;  result_w = sum_l wacc_l + L * sum_{l>=1} S_l,
+// result_run = S_0.  Output (run, wacc) per wave = per segment of 64 L slots with local weights.
+template <class C>
+__device__ __forceinline__ void wave_weighted_combine(Proj<C> run, Proj<C> wacc, int log_unit, Proj<C>* sh, int lane,
+                                                      Proj<C>& out_run, Proj<C>& out_wacc) {
+    // suffix scan of run (Hillis-Steele): S_l = sum_{j >= l} run_j
+    Proj<C> S = run;
+    for (int off = 1; off < 64; off <<= 1) {
+        st_proj<C>(sh + lane, S);
+        __syncthreads();
+        if (lane + off < 64) S = proj_add_call<C>(S, ld_proj<C>(sh + lane + off));
+        __syncthreads();
+    }
+    // V_l = wacc_l + unit * S_l (l >= 1), V_0 = wacc_0
+    Proj<C> V = wacc;
+    if (lane >= 1) {
+        Proj<C> T = S;
+        for (int d = 0; d < log_unit; d++) T = proj_dbl_call<C>(T);
+        V = proj_add_call<C>(V, T);
+    }
+    out_run = S;  // valid in lane 0
+    out_wacc = wave_tree_sum<C>(V, sh, lane);
+}
+
+template <class C>
+__global__ void __launch_bounds__(64)
+msm_reduce1_kernel(const Proj<C>* __restrict__ buckets, uint32_t nb /* valid slots per window */, uint32_t nbp /* padded */,
+                   Proj<C>* __restrict__ seg_run, Proj<C>* __restrict__ seg_wacc) {
+    extern __shared__ uint32_t lds_raw[];
+    Proj<C>* sh = reinterpret_cast<Proj<C>*>(lds_raw);
+    const int lane = threadIdx.x;
+    const uint32_t segs_per_window = nbp / (64 * MSM_REDUCE_L);
+    const uint32_t w = blockIdx.x / segs_per_window, seg = blockIdx.x % segs_per_window;
+    const uint32_t slot0 = seg * 64 * MSM_REDUCE_L + lane * MSM_REDUCE_L;
+    Proj<C> run = proj_zero<C>(), wacc = proj_zero<C>();
+    // descending: run accumulates suffixes, wacc += run after each step gives local weights 0..L-1
+    for (int i = MSM_REDUCE_L - 1; i >= 0; i--) {
+        const uint32_t slot = slot0 + i;
+        if (slot < nb && slot > 0) run = proj_add_call<C>(run, ld_proj<C>(buckets + (size_t)w * nb + slot));
+        if (i > 0) wacc = proj_add_call<C>(wacc, run);
+    }
+    Proj<C> orun, owacc;
+    int log_unit = 0;
+    while ((1 << log_unit) < MSM_REDUCE_L) log_unit++;
+    wave_weighted_combine<C>(run, wacc, log_unit, sh, lane, orun, owacc);
+    if (lane == 0) {
+        st_proj<C>(seg_run + blockIdx.x, orun);
+        st_proj<C>(seg_wacc + blockIdx.x, owacc);
+    }
+}
+
+// Level 2: one wave per window combines its segments (segs_per_window <= 64 * LSEG handled by a
+// serial loop per lane).  Segment s has weight offset s * U, U = 64 * L = 2^log_u.
+//   window_sum = sum_s wacc_s + U * sum_s s * run_s
+template <class C>
+__global__ void __launch_bounds__(64)
+msm_reduce2_kernel(const Proj<C>* __restrict__ seg_run, const Proj<C>* __restrict__ seg_wacc,
+                   uint32_t segs_per_window, int log_u, Proj<C>* __restrict__ window_sums) {
+    extern __shared__ uint32_t lds_raw[];
+    Proj<C>* sh = reinterpret_cast<Proj<C>*>(lds_raw);
+    const int lane = threadIdx.x;
+    const uint32_t w = blockIdx.x;
+    const uint32_t per_lane = (segs_per_window + 63) / 64;  // consecutive segments per lane
+    Proj<C> run = proj_zero<C>(), wacc_w = proj_zero<C>(), plain = proj_zero<C>();
+    for (int i = (int)per_lane - 1; i >= 0; i--) {
+        const uint32_t s = lane * per_lane + i;
+        if (s < segs_per_window) {
+            run = proj_add_call<C>(run, ld_proj<C>(seg_run + (size_t)w * segs_per_window + s));
+            plain = proj_add_call<C>(plain, ld_proj<C>(seg_wacc + (size_t)w * segs_per_window + s));
+        }
+        if (i > 0) wacc_w = proj_add_call<C>(wacc_w, run);
+    }
+    // lane-local: weighted (in units of U) = wacc_w ; lane offset = lane * per_lane units
+    // total units-weighted sum = sum_l wacc_w_l + per_lane * sum_{l>=1} S_l
+    Proj<C> orun, ow;
+    // per_lane need not be a power of two: multiply S_l by per_lane with a small double-and-add
+    {
+        Proj<C> S = run;
+        for (int off = 1; off < 64; off <<= 1) {
+            st_proj<C>(sh + lane, S);
+            __syncthreads();
+            if (lane + off < 64) S = proj_add_call<C>(S, ld_proj<C>(sh + lane + off));
+            __syncthreads();
+        }
+        Proj<C> V = wacc_w;
+        if (lane >= 1) {
+            Proj<C> T = proj_zero<C>();
+            for (int b = 31; b >= 0; b--) {
+                T = proj_dbl_call<C>(T);
+                if ((per_lane >> b) & 1) T = proj_add_call<C>(T, S);
+            }
+            V = proj_add_call<C>(V, T);
+        }
+        ow = wave_tree_sum<C>(V, sh, lane);
+    }
+    Proj<C> pl = wave_tree_sum<C>(plain, sh, lane);
+    if (lane == 0) {
+        for (int d = 0; d < log_u; d++) ow = proj_dbl_call<C>(ow);
+        st_proj<C>(window_sums + w, proj_add_call<C>(pl, ow));
+    }
+}
+
+}  // namespace gh

@@ -1,0 +1,3 @@
+// MSM kernels + launch sequence instantiated for mnt6753_g1 (see msm_impl.h, msm_kernels.h).
+#include "msm_impl.h"
+GH_DEFINE_MSM_OPS(gh::Mnt6G1, msm_ops_mnt6753_g1)

@@ -1,0 +1,155 @@
+// ntt.hip -- evaluation-domain tables and launch sequence of the transforms (ntt_kernels.h).
+#include "runtime.h"
+#include "ntt_kernels.h"
+#include "host_math.h"
+
+namespace gh_rt {
+using namespace gh;
+
+template <class P> struct FieldConsts;
+template <> struct FieldConsts<P6> {  // MNT4-753 Fr
+    static constexpr int two_adicity = GH_P6_TWO_ADICITY;
+    static const uint64_t* root_m() { static const uint64_t v[12] = GH_P6_ROOT_M_64; return v; }
+    static const uint64_t* gen_m() { static const uint64_t v[12] = GH_P6_GEN17_M_64; return v; }
+};
+template <> struct FieldConsts<P4> {  // MNT6-753 Fr
+    static constexpr int two_adicity = GH_P4_TWO_ADICITY;
+    static const uint64_t* root_m() { static const uint64_t v[12] = GH_P4_ROOT_M_64; return v; }
+    static const uint64_t* gen_m() { static const uint64_t v[12] = GH_P4_GEN17_M_64; return v; }
+};
+
+template <class P> int build_pow_table(Fp* tab, int log_n, const Fp& first, Fp base) {
+    HIPCHK(hipMemcpyAsync(tab, &first, sizeof(Fp), hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    for (int s = 0; s < log_n; s++) {
+        uint32_t half = 1u << s;
+        hipLaunchKernelGGL((pow_table_step_kernel<P>), dim3((half + 255) / 256), dim3(256), 0, g.stream, tab, half, base);
+        base = fp_sqr<P>(base);
+    }
+    HIPCHK(hipGetLastError());
+    return GH_OK;
+}
+
+template <class P> int get_domain(int fidx, int log_n, bool need_coset, bool need_coset_inv, Domain** out) {
+    Domain& d = g.domains[fidx][log_n];
+    const size_t N = (size_t)1 << log_n;
+    if (!d.tw) {
+        d.log_n = log_n;
+        // group_gen = ROOT_OF_UNITY^(2^(s - log_n))   (domain.rs:76-79)
+        Fp w = fp_from_abi<P>(reinterpret_cast<const uint32_t*>(FieldConsts<P>::root_m()));
+        for (int i = log_n; i < FieldConsts<P>::two_adicity; i++) w = fp_sqr<P>(w);
+        HIPCHK(hipMalloc((void**)&d.tw, N * sizeof(Fp)));
+        int rc = build_pow_table<P>(d.tw, log_n, fp_one<P>(), w);
+        if (rc) return rc;
+        // size_inv = (N as field element)^-1, internal form
+        Fp n_int = fp_one<P>();
+        for (int i = 0; i < log_n; i++) n_int = fp_dbl<P>(n_int);
+        d.size_inv = host_fp_inv<P>(n_int);
+        HIPCHK(hipMalloc((void**)&d.scratch, N * 96));
+    }
+    if (need_coset && !d.coset) {
+        Fp gen = fp_from_abi<P>(reinterpret_cast<const uint32_t*>(FieldConsts<P>::gen_m()));
+        HIPCHK(hipMalloc((void**)&d.coset, N * sizeof(Fp)));
+        int rc = build_pow_table<P>(d.coset, log_n, fp_one<P>(), gen);
+        if (rc) return rc;
+    }
+    if (need_coset_inv && !d.coset_inv) {
+        Fp gen = fp_from_abi<P>(reinterpret_cast<const uint32_t*>(FieldConsts<P>::gen_m()));
+        Fp gi = host_fp_inv<P>(gen);
+        HIPCHK(hipMalloc((void**)&d.coset_inv, N * sizeof(Fp)));
+        int rc = build_pow_table<P>(d.coset_inv, log_n, d.size_inv, gi);
+        if (rc) return rc;
+    }
+    *out = &d;
+    return GH_OK;
+}
+
+template <class P> int fft_run(int fidx, void* d_data, uint32_t log_n, uint32_t flags) {
+    if ((int)log_n >= FieldConsts<P>::two_adicity) {
+        g_err = "domain exceeds the field's 2-adicity";
+        return GH_E_UNSUPPORTED;
+    }
+    g.last_fft_ms = 0;
+    if (log_n == 0) return GH_OK;  // size-1 domain: identity (size_inv = 1, g^0 = 1)
+    const bool inverse = flags & GH_FFT_INVERSE, coset = flags & GH_FFT_COSET;
+    Domain* d;
+    int rc = get_domain<P>(fidx, (int)log_n, coset && !inverse, coset && inverse, &d);
+    if (rc) return rc;
+    const int P_ = ((int)log_n + NTT_MAX_LOGR - 1) / NTT_MAX_LOGR;
+    int ks[8];
+    {
+        int base = (int)log_n / P_, rem = (int)log_n % P_;
+        for (int s = 0; s < P_; s++) ks[s] = base + (s < rem ? 1 : 0);
+    }
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[fidx]) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt_pass_kernel<P>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, NL * 4 * NTT_MAX_TILE));
+        attr_set[fidx] = true;
+    }
+    uint32_t* bufs[2] = {(uint32_t*)d_data, d->scratch};
+    int cur = 0, log_ns = 0;
+    HIPCHK(hipEventRecord(g.ev[4], g.stream));
+    for (int s = 0; s < P_; s++) {
+        NttPassArgs A;
+        A.in = bufs[cur];
+        A.out = bufs[cur ^ 1];
+        A.tw = d->tw;
+        A.pre = (s == 0 && coset && !inverse) ? d->coset : nullptr;
+        A.post = nullptr;
+        A.has_post_scalar = 0;
+        A.post_scalar = d->size_inv;
+        if (s == P_ - 1 && inverse) {
+            if (coset) A.post = d->coset_inv; else A.has_post_scalar = 1;
+        }
+        A.log_n = (int)log_n;
+        A.k = ks[s];
+        A.log_ns = log_ns;
+        int log_c = (int)log_n - ks[s];
+        if (log_c > 10 - ks[s]) log_c = 10 - ks[s];
+        A.log_c = log_c;
+        A.inverse = inverse ? 1 : 0;
+        const int E = 1 << (ks[s] + log_c);
+        int threads = E / 2;
+        if (threads < 64) threads = 64;
+        const unsigned grid = 1u << ((int)log_n - ks[s] - log_c);
+        hipLaunchKernelGGL((ntt_pass_kernel<P>), dim3(grid), dim3(threads), (size_t)NL * 4 * E, g.stream, A);
+        cur ^= 1;
+        log_ns += ks[s];
+    }
+    HIPCHK(hipGetLastError());
+    if (cur == 1) HIPCHK(hipMemcpyAsync(d_data, d->scratch, ((size_t)96) << log_n, hipMemcpyDeviceToDevice, g.stream));
+    HIPCHK(hipEventRecord(g.ev[5], g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    HIPCHK(hipEventElapsedTime(&g.last_fft_ms, g.ev[4], g.ev[5]));
+    return GH_OK;
+}
+
+template <class P> int vec_op(int op, void* d_a, const void* d_b, const uint64_t* scalar12, size_t n) {
+    if (n == 0) return GH_OK;
+    Fp s = fp_zero();
+    if (op == 2) s = fp_from_abi<P>(reinterpret_cast<const uint32_t*>(scalar12));
+    dim3 grid((unsigned)((n + 255) / 256)), blk(256);
+    if (op == 0) hipLaunchKernelGGL((vec_op_kernel<P, 0>), grid, blk, 0, g.stream, (uint32_t*)d_a, (const uint32_t*)d_b, s, n);
+    else if (op == 1) hipLaunchKernelGGL((vec_op_kernel<P, 1>), grid, blk, 0, g.stream, (uint32_t*)d_a, (const uint32_t*)d_b, s, n);
+    else hipLaunchKernelGGL((vec_op_kernel<P, 2>), grid, blk, 0, g.stream, (uint32_t*)d_a, (const uint32_t*)d_b, s, n);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(g.stream));
+    return GH_OK;
+}
+
+
+int fft_run(gh_field_t field, void* d_data, uint32_t log_n, uint32_t flags) {
+    if (field == GH_MNT4753_FR) return fft_run<P6>(0, d_data, log_n, flags);
+    if (field == GH_MNT6753_FR) return fft_run<P4>(1, d_data, log_n, flags);
+    g_err = "unknown field id";
+    return GH_E_BAD_ARG;
+}
+int vec_op(gh_field_t field, int op, void* d_a, const void* d_b, const uint64_t* s, size_t n) {
+    if (field == GH_MNT4753_FR) return vec_op<P6>(op, d_a, d_b, s, n);
+    if (field == GH_MNT6753_FR) return vec_op<P4>(op, d_a, d_b, s, n);
+    g_err = "unknown field id";
+    return GH_E_BAD_ARG;
+}
+
+}  // namespace gh_rt

@@ -1,0 +1,85 @@
+// runtime.h -- process-wide device context shared by the translation units of libginger_hip.so
+// (one TU per curve so that hipcc can build them in parallel; see __graft_entry__.py build()).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <map>
+#include <mutex>
+#include <string>
+#include "../../include/ginger_hip.h"
+#include "fp29.h"
+
+namespace gh_rt {
+
+struct Domain {
+    int log_n = 0;
+    gh::Fp* tw = nullptr;          // w^i
+    gh::Fp* coset = nullptr;       // g^i
+    gh::Fp* coset_inv = nullptr;   // size_inv * g^-i
+    gh::Fp size_inv;               // internal form
+    uint32_t* scratch = nullptr;
+};
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+struct Ctx {
+    bool ready = false;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[8];
+    std::map<int, Domain> domains[2];
+    std::map<std::string, DevBuf> pool;
+    int window_override = 0;
+    gh_msm_timing_t last_msm{};
+    float last_fft_ms = 0;
+};
+
+extern Ctx g;
+extern std::string g_err;
+
+int ensure_init();
+int pool_get(const char* name, size_t bytes, void** out);
+int device_scan(const uint32_t* in, uint32_t* out, size_t n, const char* tmpname);
+int auto_window(size_t n);
+
+#define HIPCHK(call)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            char b_[512];                                                                    \
+            snprintf(b_, sizeof b_, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            gh_rt::g_err = b_;                                                               \
+            return e_ == hipErrorOutOfMemory ? GH_E_NOMEM : GH_E_HIP;                        \
+        }                                                                                    \
+    } while (0)
+
+// ---- per-curve entry points (msm_<curve>.hip)
+struct BasesBase {
+    gh_curve_t curve;
+    size_t n = 0;
+    void* d_points = nullptr;   // n x Aff<C>, internal layout
+    uint8_t* d_inf = nullptr;   // n bytes or null
+    uint32_t magic = 0x6768424au;
+};
+struct MsmOps {
+    int (*upload)(const uint64_t* bases, const uint8_t* infinity, size_t n, BasesBase** out);
+    int (*run)(BasesBase* h, const void* d_scalars, size_t n_scalars, uint64_t* out_xyz);
+    int (*host)(const uint64_t* bases, const uint8_t* infinity, size_t n_bases, const uint64_t* scalars,
+                size_t n_scalars, uint64_t* out_xyz);
+    int (*proj_add)(uint64_t* acc_xyz, const uint64_t* p_xyz);
+    int (*to_affine)(const uint64_t* xyz, uint64_t* out_xy, uint8_t* is_infinity);
+};
+const MsmOps* msm_ops_mnt4753_g1();
+const MsmOps* msm_ops_mnt4753_g2();
+const MsmOps* msm_ops_mnt6753_g1();
+const MsmOps* msm_ops_mnt6753_g2();
+
+// ---- transforms (ntt.hip)
+int fft_run(gh_field_t field, void* d_data, uint32_t log_n, uint32_t flags);
+int vec_op(gh_field_t field, int op, void* d_a, const void* d_b, const uint64_t* scalar12, size_t n);
+
+}  // namespace gh_rt

@@ -1,0 +1,164 @@
+/* ginger_hip.h -- C ABI of the MI355X (gfx950) implementation of ginger-lib's Groth16 prover hot
+ * path: variable-base multi-scalar multiplication over MNT4-753 / MNT6-753 G1 and G2, and the
+ * radix-2 evaluation-domain transforms over their scalar fields.
+ *
+ * The reference (ZencashOfficial/ginger-lib, 100 % Rust) has no FFI; these entry points are what
+ * a `#[cfg(feature = "gpu")]` dispatch inside the two reference modules would bind
+ * (INTEGRATION.md shows the Rust `extern "C"` block and the safe wrappers):
+ *
+ *   algebra/src/msm/variable_base.rs:85-90   VariableBaseMSM::multi_scalar_mul   -> gh_msm_*
+ *   algebra/src/fft/domain.rs:65-94          EvaluationDomain::new                -> gh_domain_supported
+ *   algebra/src/fft/domain.rs:113-138        fft / fft_in_place / ifft(_in_place) -> gh_fft_*
+ *   algebra/src/fft/domain.rs:155-179        coset_fft / coset_ifft (_in_place)   -> gh_fft_* + GH_FFT_COSET
+ *   algebra/src/fft/domain.rs:245-256        divide_by_vanishing_poly_on_coset_in_place -> gh_vec_scale_*
+ *   algebra/src/fft/domain.rs:289-302        mul_polynomials_in_evaluation_domain -> gh_vec_mul_*
+ *
+ * Data formats (exactly the reference's in-memory values, marshalled field by field because the
+ * Rust structs are not repr(C) -- SURVEY.md section 8b):
+ *   field element  : 12 little-endian uint64_t limbs (BigInteger768, biginteger/macros.rs:4),
+ *                    MONTGOMERY form with R = 2^768 (fp_768.rs:24-30) for curve coordinates and
+ *                    FFT data; CANONICAL integers (< r) for MSM scalars (what `into_repr()` yields,
+ *                    groth16/prover.rs:241-267).
+ *   G1 affine base : x || y                       = 24 u64, plus one uint8_t infinity flag
+ *   MNT4 G2 base   : x.c0 x.c1 y.c0 y.c1          = 48 u64        (Fq2, fields/models/fp2.rs)
+ *   MNT6 G2 base   : x.c0 x.c1 x.c2 y.c0 y.c1 y.c2 = 72 u64       (Fq3, fields/models/fp3.rs)
+ *   MSM result     : homogeneous projective X || Y || Z (each one base-field element, same
+ *                    component order), Z == 0 <=> infinity (short_weierstrass_projective.rs:285-290,
+ *                    :372-390).  As in the reference, only the affine image X/Z, Y/Z is canonical.
+ *
+ * Every function returns GH_OK (0) or a negative GH_E_* code; nothing is thrown, no host pointer
+ * is retained after return.  Calls are serialised by an internal lock and may come from any thread.
+ * There is NO CPU fallback inside this library: without a usable gfx950 device every call fails
+ * with GH_E_NO_DEVICE (the Rust shim decides what to do with a non-zero status).
+ */
+#ifndef GINGER_HIP_H
+#define GINGER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GH_OK 0
+#define GH_E_BAD_ARG (-1)       /* null pointer, inconsistent lengths */
+#define GH_E_UNSUPPORTED (-2)   /* domain too large for the field's 2-adicity (domain.rs:69-71) or for memory */
+#define GH_E_NO_DEVICE (-3)     /* no gfx950 device / HIP runtime unusable */
+#define GH_E_HIP (-4)           /* a HIP runtime call failed; see gh_last_error() */
+#define GH_E_NOMEM (-5)
+#define GH_E_BAD_HANDLE (-6)
+
+#define GH_FFT_INVERSE 1u /* ifft: use group_gen^-1 and multiply by size_inv (domain.rs:134-138) */
+#define GH_FFT_COSET 2u   /* coset variant: distribute_powers with g = 17 (domain.rs:140-179) */
+
+/* Curves / fields are selected by id so that one entry point serves the four instantiations. */
+typedef enum {
+    GH_MNT4753_G1 = 0, /* base field p4, scalars mod p6                           */
+    GH_MNT4753_G2 = 1, /* base field Fq2 = p4[X]/(X^2-13)                         */
+    GH_MNT6753_G1 = 2, /* base field p6, scalars mod p4                           */
+    GH_MNT6753_G2 = 3  /* base field Fq3 = p6[X]/(X^3-11)                         */
+} gh_curve_t;
+
+typedef enum {
+    GH_MNT4753_FR = 0, /* = MNT6-753 Fq, 2-adicity 30 (fields/mnt6753/fq.rs:93)   */
+    GH_MNT6753_FR = 1  /* = MNT4-753 Fq, 2-adicity 15 (fields/mnt4753/fq.rs:94)   */
+} gh_field_t;
+
+/* ---- lifecycle ------------------------------------------------------------------------- */
+/* Bind this process to one GPU.  devices == NULL selects $LOCAL_RANK (or 0).  Only devices[0]
+ * is used: the deployment model is one process per GPU (multi-GPU MSM: ginger_hip_dist.h /
+ * the Python launcher shard pairs across ranks and fold the partial sums). Idempotent. */
+int gh_init(const int* devices, int n_devices);
+int gh_shutdown(void);
+const char* gh_last_error(void);
+/* Human-readable device line ("AMD Instinct MI355X, 256 CUs, gfx950"); valid until gh_shutdown. */
+const char* gh_device_name(void);
+
+/* ---- multi-scalar multiplication -------------------------------------------------------- */
+/* out = sum_{i < min(n_bases, n_scalars)} scalars[i] * bases[i]
+ * Semantics of variable_base.rs:10-83: zip-truncation to the shorter input, zero scalars and
+ * infinity bases contribute nothing, empty input -> (0, 1, 0).
+ *   bases      n_bases  * (24 * deg) u64   (deg = 1, 2, 3 by curve)
+ *   infinity   n_bases  bytes (non-zero = point at infinity), may be NULL (= none)
+ *   scalars    n_scalars * 12 u64, canonical
+ *   out_xyz    3 * 12 * deg u64                                                          */
+int gh_msm(gh_curve_t curve, const uint64_t* bases, const uint8_t* infinity, size_t n_bases,
+           const uint64_t* scalars, size_t n_scalars, uint64_t* out_xyz);
+
+/* Bases are static per proving key (groth16/mod.rs:158-170): upload once, reuse per proof. */
+typedef struct gh_bases* gh_bases_t;
+int gh_bases_upload(gh_curve_t curve, const uint64_t* bases, const uint8_t* infinity, size_t n_bases,
+                    gh_bases_t* out_handle);
+int gh_bases_free(gh_bases_t handle);
+size_t gh_bases_len(gh_bases_t handle);
+/* scalars on the host */
+int gh_msm_resident(gh_bases_t handle, const uint64_t* scalars, size_t n_scalars, uint64_t* out_xyz);
+/* scalars already in device memory (from gh_dev_alloc); used by the benchmark's HBM-resident timing
+ * and by a device-resident prover pipeline.  The call is synchronous on the library stream. */
+int gh_msm_resident_dev(gh_bases_t handle, const void* d_scalars, size_t n_scalars, uint64_t* out_xyz);
+
+/* Window size override for sweeps (0 = automatic).  Affects subsequent MSM calls. */
+int gh_msm_set_window(int c);
+int gh_msm_get_window(gh_curve_t curve, size_t n);
+
+/* Time spent by the last MSM call in its phases, milliseconds (device phases by HIP events on the
+ * library stream, host fold by a host clock).  Any pointer may be NULL. */
+typedef struct {
+    float sort_ms;        /* digit extraction + bucket sort */
+    float accumulate_ms;  /* bucket accumulation kernel (dominant) */
+    float reduce_ms;      /* bucket running-sum reduction kernels */
+    float fold_ms;        /* window fold (host) + D2H of window sums */
+    float total_ms;
+    int window_bits;
+    int num_windows;
+    unsigned long long accumulate_madds; /* mixed additions issued by the accumulate kernel */
+} gh_msm_timing_t;
+int gh_msm_last_timing(gh_msm_timing_t* out);
+
+/* ---- evaluation-domain transforms -------------------------------------------------------- */
+/* 1 if EvaluationDomain::new(num_coeffs) would be Some(..) (domain.rs:65-72), else 0;
+ * *log_n receives log2(next_power_of_two(num_coeffs)).                                     */
+int gh_domain_supported(gh_field_t field, size_t num_coeffs, uint32_t* log_n);
+
+/* out[0 .. 2^log_n) = transform of `in` padded with zeros / truncated to 2^log_n elements
+ * (Vec::resize in domain.rs:121,135).  in/out are host arrays of 12-u64 Montgomery elements and
+ * may alias.  flags: 0 = fft, GH_FFT_INVERSE = ifft, GH_FFT_COSET = coset_fft,
+ * GH_FFT_INVERSE | GH_FFT_COSET = coset_ifft.  Natural order in and out.                    */
+int gh_fft(gh_field_t field, const uint64_t* in, size_t n_in, uint64_t* out, uint32_t log_n, uint32_t flags);
+
+/* Device-resident variant: d_data holds 2^log_n elements in device memory and is transformed in
+ * place (a library-owned scratch buffer of the same size is used internally).               */
+int gh_fft_dev(gh_field_t field, void* d_data, uint32_t log_n, uint32_t flags);
+
+/* Pointwise helpers on device-resident vectors of n elements (witness_map glue,
+ * groth16/r1cs_to_qap.rs:137-166):  a[i] = a[i] * b[i];  a[i] = a[i] - b[i];  a[i] = a[i] * s  */
+int gh_vec_mul_dev(gh_field_t field, void* d_a, const void* d_b, size_t n);
+int gh_vec_sub_dev(gh_field_t field, void* d_a, const void* d_b, size_t n);
+int gh_vec_scale_dev(gh_field_t field, void* d_a, const uint64_t* scalar12, size_t n);
+/* Host-buffer forms of the same (copy in, compute, copy out). */
+int gh_vec_mul(gh_field_t field, uint64_t* a, const uint64_t* b, size_t n);
+int gh_vec_scale(gh_field_t field, uint64_t* a, const uint64_t* scalar12, size_t n);
+
+/* Duration of the kernels of the last gh_fft / gh_fft_dev call (HIP events), milliseconds. */
+int gh_fft_last_kernel_ms(float* ms);
+
+/* ---- device memory (plain pointers; for callers that keep vectors resident) -------------- */
+int gh_dev_alloc(void** d_ptr, size_t bytes);
+int gh_dev_free(void* d_ptr);
+int gh_dev_upload(void* d_dst, const void* h_src, size_t bytes);
+int gh_dev_download(void* h_dst, const void* d_src, size_t bytes);
+int gh_dev_sync(void);
+
+/* ---- group helpers on the host side of the boundary -------------------------------------- */
+/* acc = acc + p for two projective points in the MSM result format (used to fold the per-GPU
+ * partial sums after the all-gather: SURVEY.md section 8e).  Runs on the host; no device needed. */
+int gh_proj_add(gh_curve_t curve, uint64_t* acc_xyz, const uint64_t* p_xyz);
+/* x||y (Montgomery) and *is_infinity from a projective result: the reference's into_affine()
+ * (short_weierstrass_projective.rs:663-678).  Runs on the host.                              */
+int gh_proj_to_affine(gh_curve_t curve, const uint64_t* xyz, uint64_t* out_xy, uint8_t* is_infinity);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GINGER_HIP_H */

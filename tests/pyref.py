@@ -91,10 +91,19 @@ class Ext:
         return r
 
     def inv(self, a):
+        p, nr = self.p, self.nr
         if self.k == 1:
-            return (pow(a[0], -1, self.p),)
-        # a^(p^k - 2)
-        return self.pow(a, self.p ** self.k - 2)
+            return (pow(a[0], -1, p),)
+        if self.k == 2:  # (a0 - a1 X) / (a0^2 - nr a1^2)
+            n = pow((a[0] * a[0] - nr * a[1] * a[1]) % p, -1, p)
+            return ((a[0] * n) % p, (-a[1] * n) % p)
+        # k == 3: adjugate / norm
+        a0, a1, a2 = a
+        c0 = (a0 * a0 - nr * a1 * a2) % p
+        c1 = (nr * a2 * a2 - a0 * a1) % p
+        c2 = (a1 * a1 - a0 * a2) % p
+        n = pow((a0 * c0 + nr * (a2 * c1 + a1 * c2)) % p, -1, p)
+        return ((c0 * n) % p, (c1 * n) % p, (c2 * n) % p)
 
     def is_zero(self, a):
         return all(x == 0 for x in a)
