@@ -1,0 +1,166 @@
+"""Shared test helpers: ctypes binding of the CPU oracle (oracle/liboracle.so), (de)serialisation
+between Python ints and the ABI layouts, deterministic input generation.  Test infrastructure."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+import pyref
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_SO = os.path.join(ROOT, "oracle", "liboracle.so")
+CURVE_ID = {"mnt4753_g1": 0, "mnt4753_g2": 1, "mnt6753_g1": 2, "mnt6753_g2": 3}
+FIELD_ID = {"mnt4753_fr": 0, "mnt6753_fr": 1}
+FIELD_OF = {"mnt4753_fr": pyref.P6, "mnt6753_fr": pyref.P4}
+
+_oracle = None
+
+
+def oracle():
+    global _oracle
+    if _oracle is None:
+        if not os.path.exists(ORACLE_SO):
+            subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+        lib = ctypes.CDLL(ORACLE_SO)
+        vp, sz, ci, u32 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_uint32
+        lib.oracle_fp_op.argtypes = [ci, ci, vp, vp, vp]
+        lib.oracle_ext_op.argtypes = [ci, ci, vp, vp, vp]
+        lib.oracle_ec_op.argtypes = [ci, ci, vp, vp, ci, vp]
+        lib.oracle_msm.argtypes = [ci, vp, vp, sz, vp, sz, vp, ci]
+        lib.oracle_fft.argtypes = [ci, vp, sz, u32, u32, ci]
+        lib.oracle_fft_variant.argtypes = [ci, vp, u32, ci]
+        lib.oracle_domain.argtypes = [ci, sz, vp, ctypes.POINTER(u32)]
+        lib.oracle_vec_mul.argtypes = [ci, vp, vp, sz]
+        lib.oracle_vanishing_inv_on_coset.argtypes = [ci, u32, vp]
+        _oracle = lib
+    return _oracle
+
+
+def ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p) if a is not None and a.size else None
+
+
+def u64(x, n=12):
+    return np.array(pyref.int_to_limbs(x, n), dtype=np.uint64)
+
+
+def to_int(arr):
+    return pyref.limbs_to_int([int(v) for v in arr])
+
+
+# ---- field element arrays (Montgomery, ABI layout)
+def fe_array(F, vals):
+    out = np.zeros((len(vals), 12), dtype=np.uint64)
+    for i, v in enumerate(vals):
+        out[i] = pyref.int_to_limbs(F.to_mont(v))
+    return out
+
+
+def fe_list(F, arr):
+    arr = np.asarray(arr, dtype=np.uint64).reshape(-1, 12)
+    return [F.from_mont(pyref.limbs_to_int([int(v) for v in r])) for r in arr]
+
+
+def scalar_array(vals):
+    out = np.zeros((len(vals), 12), dtype=np.uint64)
+    for i, v in enumerate(vals):
+        out[i] = pyref.int_to_limbs(v)
+    return out
+
+
+def bases_array(C, pts):
+    k = C.deg
+    out = np.zeros((len(pts), 24 * k), dtype=np.uint64)
+    inf = np.zeros(len(pts), dtype=np.uint8)
+    for i, P in enumerate(pts):
+        if P is None:
+            inf[i] = 1
+            continue
+        out[i, :12 * k] = pyref.ext_to_abi(C.F, P[0])
+        out[i, 12 * k:] = pyref.ext_to_abi(C.F, P[1])
+    return out, inf
+
+
+def proj_array(C, P, z=None):
+    """affine point (or None) -> projective ABI array with an arbitrary non-trivial Z"""
+    k = C.deg
+    E = C.E
+    if P is None:
+        X, Y, Z = E.zero(), E.one(), E.zero()
+    else:
+        z = z or tuple((7 + 3 * i) for i in range(k))
+        X, Y, Z = E.mul(P[0], z), E.mul(P[1], z), z
+    return np.array(pyref.ext_to_abi(C.F, X) + pyref.ext_to_abi(C.F, Y) + pyref.ext_to_abi(C.F, Z), dtype=np.uint64)
+
+
+def affine_of_xyz(C, xyz):
+    k = C.deg
+    v = [int(x) for x in np.asarray(xyz).reshape(-1)]
+    X = pyref.ext_from_abi(C.F, v[0:12 * k], k)
+    Y = pyref.ext_from_abi(C.F, v[12 * k:24 * k], k)
+    Z = pyref.ext_from_abi(C.F, v[24 * k:36 * k], k)
+    return C.proj_to_affine(X, Y, Z)
+
+
+def chain_points(C, n, rng):
+    """n distinct curve points P_0 + i H (cheap: one affine addition each)."""
+    H = C.mul(rng.next_u64() | 1, C.G)
+    P = C.mul(rng.next_u64() | 1, C.G)
+    pts = []
+    for _ in range(n):
+        pts.append(P)
+        P = C.add(P, H)
+    return pts
+
+
+def random_scalars_np(n, modulus_bits_top=49, seed=1, below=None):
+    """n uniform 12-limb integers with the top limb masked to 49 bits (algebra/src/fields/macros.rs:11-28);
+    values >= `below` (if given) are resampled -- vectorised for the full-size GPU tests."""
+    rng = np.random.default_rng(seed)
+    s = rng.integers(0, 1 << 64, size=(n, 12), dtype=np.uint64)
+    s[:, 11] &= np.uint64((1 << modulus_bits_top) - 1)
+    if below is not None:
+        top = np.uint64(below >> 704)
+        bad = s[:, 11] >= top      # conservative: force the top limb strictly below the modulus' top limb
+        while bad.any():
+            s[bad, 11] = rng.integers(0, int(top), size=int(bad.sum()), dtype=np.uint64)
+            bad = s[:, 11] >= top
+    return s
+
+
+# ---- oracle wrappers
+def oracle_msm(curve, bases, inf, scalars, threads=8):
+    C = pyref.CURVES[curve]
+    bases = np.ascontiguousarray(bases, dtype=np.uint64)
+    scalars = np.ascontiguousarray(scalars, dtype=np.uint64)
+    out = np.zeros(36 * C.deg, dtype=np.uint64)
+    n_b = bases.size // (24 * C.deg)
+    n_s = scalars.size // 12
+    infp = None
+    if inf is not None:
+        inf = np.ascontiguousarray(inf, dtype=np.uint8)
+        infp = ptr(inf)
+    rc = oracle().oracle_msm(CURVE_ID[curve], ptr(bases), infp, n_b, ptr(scalars), n_s, ptr(out), threads)
+    assert rc == 0
+    return out
+
+
+def oracle_affine(curve, xyz):
+    C = pyref.CURVES[curve]
+    xyz = np.ascontiguousarray(xyz, dtype=np.uint64)
+    out = np.zeros(24 * C.deg, dtype=np.uint64)
+    inf = oracle().oracle_ec_op(CURVE_ID[curve], 4, ptr(xyz), None, 0, ptr(out))
+    return out, bool(inf)
+
+
+def oracle_fft(field, a, log_n, flags, threads=8):
+    """same contract as gh_fft: pad/truncate to 2^log_n, transform, return N x 12 u64"""
+    n = 1 << log_n
+    a = np.asarray(a, dtype=np.uint64).reshape(-1, 12)
+    n_in = min(len(a), n)
+    buf = np.zeros((n, 12), dtype=np.uint64)
+    buf[:n_in] = a[:n_in]
+    rc = oracle().oracle_fft(FIELD_ID[field], ptr(buf), n_in, log_n, flags, threads)
+    assert rc == 0
+    return buf

@@ -1,0 +1,105 @@
+"""CPU oracle vs the first-principles golden vectors (tests/golden/{msm,ntt}_golden.json) and the
+algebraic identities the reference itself tests: naive == Pippenger incl. unequal lengths
+(variable_base.rs:102-151), ifft(fft) = id and coset round trip (fft/test.rs:9-43),
+parallel_fft == serial_fft (fft/test.rs:45-72)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import pyref
+import support as S
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+MSM = json.load(open(os.path.join(G, "msm_golden.json")))
+NTT = json.load(open(os.path.join(G, "ntt_golden.json")))
+
+
+def load_msm_case(name):
+    case = MSM[name]
+    curve = name.replace("_zero_sum", "")
+    C = pyref.CURVES[curve]
+    pts = [None if b is None else (tuple(int(c, 16) for c in b[0]), tuple(int(c, 16) for c in b[1])) for b in case["bases"]]
+    scal = [int(s, 16) for s in case["scalars"]]
+    e = case["expected_affine"]
+    exp = None if e is None else (tuple(int(c, 16) for c in e[0]), tuple(int(c, 16) for c in e[1]))
+    return curve, C, pts, scal, exp
+
+
+@pytest.mark.parametrize("name", list(MSM))
+def test_oracle_msm_golden(name):
+    curve, C, pts, scal, exp = load_msm_case(name)
+    b, inf = S.bases_array(C, pts)
+    for threads in (1, 4):
+        out = S.oracle_msm(curve, b, inf, S.scalar_array(scal), threads)
+        assert S.affine_of_xyz(C, out) == exp
+
+
+@pytest.mark.parametrize("name", list(NTT))
+def test_oracle_ntt_golden(name):
+    case = NTT[name]
+    F = S.FIELD_OF[case["field"]]
+    a = S.fe_array(F, [int(x, 16) for x in case["input"]])
+    for nm, flags in (("fft", 0), ("ifft", 1), ("coset_fft", 2), ("coset_ifft", 3)):
+        for threads in (1, 2, 8):
+            got = S.fe_list(F, S.oracle_fft(case["field"], a, case["log_n"], flags, threads))
+            assert got == [int(x, 16) for x in case[nm]], (name, nm, threads)
+
+
+def test_oracle_msm_empty_and_small():
+    for curve, C in pyref.CURVES.items():
+        out = S.oracle_msm(curve, np.zeros((0, 24 * C.deg), np.uint64), None, np.zeros((0, 12), np.uint64))
+        assert S.affine_of_xyz(C, out) is None
+        # (0, 1, 0): swp.rs:372-378
+        k = C.deg
+        assert pyref.ext_from_abi(C.F, [int(v) for v in out[12 * k:24 * k]], k) == C.E.one()
+
+
+def test_oracle_msm_vs_naive_window_regimes():
+    """len < 32 -> c = 3 (251 windows); len >= 32 -> c from the log2 formula (variable_base.rs:14-18)"""
+    rng = pyref.Rng(99)
+    C = pyref.CURVES["mnt4753_g1"]
+    for n in (5, 31, 32, 100):
+        pts = S.chain_points(C, n, rng)
+        scal = [rng.field_elem(C.order) for _ in range(n)]
+        b, inf = S.bases_array(C, pts)
+        out = S.oracle_msm("mnt4753_g1", b, inf, S.scalar_array(scal), 8)
+        assert S.affine_of_xyz(C, out) == C.msm(pts, scal)
+    # unequal lengths: zip truncates (variable_base.rs:134-151)
+    out = S.oracle_msm("mnt4753_g1", b[:60], inf[:60], S.scalar_array(scal), 8)
+    assert S.affine_of_xyz(C, out) == C.msm(pts[:60], scal)
+
+
+@pytest.mark.parametrize("field", ["mnt4753_fr", "mnt6753_fr"])
+def test_oracle_fft_roundtrip_and_variants(field):
+    F = S.FIELD_OF[field]
+    rng = pyref.Rng(5)
+    for log_n in (0, 1, 4, 9):
+        n = 1 << log_n
+        vals = [rng.field_elem(F.p) for _ in range(n)]
+        a = S.fe_array(F, vals)
+        f = S.oracle_fft(field, a, log_n, 0, 8)
+        assert S.fe_list(F, f) == pyref.ntt_fast(F, vals, log_n)
+        assert S.fe_list(F, S.oracle_fft(field, f, log_n, 1, 8)) == vals
+        c = S.oracle_fft(field, a, log_n, 2, 8)
+        assert S.fe_list(F, S.oracle_fft(field, c, log_n, 3, 8)) == vals
+        if log_n >= 4:   # parallel_fft == serial_fft for every log_cpus (fft/test.rs:45-72)
+            ser = a.copy()
+            S.oracle().oracle_fft_variant(S.FIELD_ID[field], S.ptr(ser), log_n, -1)
+            for log_cpus in (1, 2, 3):
+                par = a.copy()
+                S.oracle().oracle_fft_variant(S.FIELD_ID[field], S.ptr(par), log_n, log_cpus)
+                assert (par == ser).all()
+
+
+def test_oracle_domain_limits():
+    import ctypes
+    out = np.zeros(48, dtype=np.uint64)
+    lg = ctypes.c_uint32()
+    o = S.oracle()
+    assert o.oracle_domain(0, 1 << 29, S.ptr(out), ctypes.byref(lg)) == 1 and lg.value == 29
+    assert o.oracle_domain(0, (1 << 29) + 1, S.ptr(out), ctypes.byref(lg)) == 0      # log >= two-adicity 30 -> None (domain.rs:69-71)
+    assert o.oracle_domain(1, 1 << 14, S.ptr(out), ctypes.byref(lg)) == 1
+    assert o.oracle_domain(1, (1 << 14) + 1, S.ptr(out), ctypes.byref(lg)) == 0      # MNT6 Fr: two-adicity 15
+    assert o.oracle_domain(0, 0, S.ptr(out), ctypes.byref(lg)) == 1 and lg.value == 0  # new(0) -> size 1

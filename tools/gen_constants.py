@@ -229,6 +229,8 @@ def main():
     L.append("")
     os.makedirs(os.path.dirname(OUT_H), exist_ok=True)
     open(OUT_H, "w").write("\n".join(L))
+    # the oracle keeps its own copy so that it does not include anything from the product tree
+    open(os.path.join(os.path.dirname(__file__), "..", "oracle", "constants_gen.h"), "w").write("\n".join(L))
     print("wrote", os.path.normpath(OUT_H), "and", os.path.normpath(OUT_J))
 
 
