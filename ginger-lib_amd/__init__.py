@@ -43,9 +43,10 @@ class GingerHipError(RuntimeError):
 
 
 class MsmTiming(ctypes.Structure):
-    _fields_ = [("sort_ms", ctypes.c_float), ("accumulate_ms", ctypes.c_float), ("reduce_ms", ctypes.c_float),
-                ("fold_ms", ctypes.c_float), ("total_ms", ctypes.c_float), ("window_bits", ctypes.c_int),
-                ("num_windows", ctypes.c_int), ("accumulate_madds", ctypes.c_ulonglong)]
+    _fields_ = [("sort_ms", ctypes.c_float), ("accumulate_ms", ctypes.c_float), ("heavy_ms", ctypes.c_float),
+                ("reduce_ms", ctypes.c_float), ("fold_ms", ctypes.c_float), ("total_ms", ctypes.c_float),
+                ("window_bits", ctypes.c_int), ("num_windows", ctypes.c_int), ("accumulate_madds", ctypes.c_ulonglong),
+                ("heavy_buckets", ctypes.c_uint)]
 
 
 _lib = None

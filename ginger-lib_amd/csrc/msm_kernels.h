@@ -14,9 +14,9 @@
 //   4. msm_accumulate_kernel one thread per bucket walks its list: gather the base (internal
 //                            layout, 208 B for G1), conditional negate, projective mixed add
 //                            (ec29.h proj_madd, 11 Fp-mul).  ~94 % of all work (as in the reference).
-//      msm_heavy_kernel      buckets longer than HEAVY_THRESHOLD are split over the lanes of a
-//                            wave and tree-reduced through LDS (skewed real-world witnesses: many
-//                            equal small scalars land in one bucket).
+//      msm_heavy_*_kernel    buckets longer than the heavy threshold (4x the mean) are cut into
+//                            chunks summed by one wave each, then combined (skewed real-world
+//                            witnesses -- many equal small scalars -- and the top window).
 //   5. msm_reduce1/2_kernel  sum_b b * B_b per window without the reference's per-window inversion:
 //                            each lane serially folds L consecutive buckets (running sum), then the
 //                            64 lanes of the wave combine their (run, weighted) pairs with a
@@ -31,8 +31,9 @@
 namespace gh {
 
 constexpr int MSM_REDUCE_L = 8;          // buckets folded serially per lane in reduce level 1
-constexpr int MSM_HEAVY_THRESHOLD = 1024;  // bucket sizes above this go to the wave-cooperative path
-constexpr int MSM_SIZE_BINS = MSM_HEAVY_THRESHOLD + 2;
+constexpr int MSM_MAX_HEAVY_THRESHOLD = 1024;  // upper bound of the run-time heavy threshold
+constexpr int MSM_SIZE_BINS = MSM_MAX_HEAVY_THRESHOLD + 2;
+constexpr int MSM_HEAVY_CHUNK = 256;           // entries of a heavy bucket summed by one wave
 
 // ---------------------------------------------------------------- generic point load / store
 template <class C> __device__ __forceinline__ Aff<C> ld_aff(const Aff<C>* p) {
@@ -115,21 +116,50 @@ msm_digits_kernel(const uint32_t* __restrict__ scalars, const uint8_t* __restric
 }
 
 // ---------------------------------------------------------------- 2b. bucket order by descending size
-// size bin = min(count, HEAVY_THRESHOLD + 1); bins are laid out so that larger sizes come first.
-static __global__ void __launch_bounds__(256) msm_size_hist_kernel(const uint32_t* counts, size_t total, uint32_t* size_hist) {
-    size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= total) return;
-    uint32_t cnt = counts[g];
-    uint32_t bin = cnt > (uint32_t)MSM_HEAVY_THRESHOLD ? (uint32_t)MSM_HEAVY_THRESHOLD + 1 : cnt;
-    atomicAdd(&size_hist[MSM_SIZE_BINS - 1 - bin], 1u);  // reversed: big first
+// size bin = min(count, heavy_thr + 1); bins are laid out so that larger sizes come first, i.e.
+// order[0 .. n_heavy) are the heavy buckets (count > heavy_thr).  Bucket sizes cluster around the
+// mean, so the bins are aggregated in LDS per block before touching the global counters.
+static __device__ __forceinline__ uint32_t msm_size_bin(uint32_t cnt, uint32_t heavy_thr) {
+    uint32_t bin = cnt > heavy_thr ? heavy_thr + 1 : cnt;
+    return heavy_thr + 1 - bin;  // reversed: heavy -> 0, then sizes heavy_thr .. 0
 }
-static __global__ void __launch_bounds__(256) msm_size_scatter_kernel(const uint32_t* counts, size_t total, uint32_t* size_cursor, uint32_t* order) {
+static __global__ void __launch_bounds__(256)
+msm_size_hist_kernel(const uint32_t* counts, size_t total, uint32_t heavy_thr, uint32_t* size_hist) {
+    __shared__ uint32_t h[MSM_SIZE_BINS];
+    for (int i = threadIdx.x; i < MSM_SIZE_BINS; i += 256) h[i] = 0;
+    __syncthreads();
     size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= total) return;
-    uint32_t cnt = counts[g];
-    uint32_t bin = cnt > (uint32_t)MSM_HEAVY_THRESHOLD ? (uint32_t)MSM_HEAVY_THRESHOLD + 1 : cnt;
-    uint32_t pos = atomicAdd(&size_cursor[MSM_SIZE_BINS - 1 - bin], 1u);
-    order[pos] = (uint32_t)g;
+    if (g < total) atomicAdd(&h[msm_size_bin(counts[g], heavy_thr)], 1u);
+    __syncthreads();
+    for (int i = threadIdx.x; i < MSM_SIZE_BINS; i += 256) if (h[i]) atomicAdd(&size_hist[i], h[i]);
+}
+static __global__ void __launch_bounds__(256)
+msm_size_scatter_kernel(const uint32_t* counts, size_t total, uint32_t heavy_thr, uint32_t* size_cursor, uint32_t* order) {
+    __shared__ uint32_t h[MSM_SIZE_BINS];
+    for (int i = threadIdx.x; i < MSM_SIZE_BINS; i += 256) h[i] = 0;
+    __syncthreads();
+    size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t bin = 0, rank = 0;
+    if (g < total) { bin = msm_size_bin(counts[g], heavy_thr); rank = atomicAdd(&h[bin], 1u); }
+    __syncthreads();
+    for (int i = threadIdx.x; i < MSM_SIZE_BINS; i += 256) { uint32_t c = h[i]; if (c) h[i] = atomicAdd(&size_cursor[i], c); }
+    __syncthreads();
+    if (g < total) order[h[bin] + rank] = (uint32_t)g;
+}
+
+// plan[0] = n_heavy, plan[1] = total number of chunks; chunk_start[h] for h in [0, n_heavy]
+static __global__ void msm_heavy_plan_kernel(const uint32_t* size_hist, const uint32_t* counts, const uint32_t* order,
+                                             uint32_t* chunk_start, uint32_t* plan) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const uint32_t n_heavy = size_hist[0];
+    uint32_t run = 0;
+    for (uint32_t h = 0; h < n_heavy; h++) {
+        chunk_start[h] = run;
+        run += (counts[order[h]] + MSM_HEAVY_CHUNK - 1) / MSM_HEAVY_CHUNK;
+    }
+    chunk_start[n_heavy] = run;
+    plan[0] = n_heavy;
+    plan[1] = run;
 }
 
 // ---------------------------------------------------------------- 3. scatter
@@ -147,24 +177,67 @@ msm_scatter_kernel(const int32_t* __restrict__ digits, size_t n, int num_windows
 }
 
 // ---------------------------------------------------------------- 4. bucket accumulation
-// order[] lists bucket ids by descending size: [0, n_heavy) are heavy (handled by msm_heavy_kernel),
+// order[] lists bucket ids by descending size: [0, n_heavy) are heavy (msm_heavy_*_kernel),
 // the rest is walked here one bucket per thread; empty buckets store infinity.
-template <class C>
-__global__ void __launch_bounds__(256)
+//
+// The loop body holds exactly ONE mixed addition and no function call, so the kernel's register
+// budget is its own.  The reference's `P == Q -> double` branch (swp.rs:492-495) is reached when a
+// bucket's running sum equals the incoming base (duplicate bases); instead of a doubling formula
+// the thread then takes a three-step detour through a fixed "salt" point S (S = G or 2G, whichever
+// has x != q.x, so q != +-S):  acc <- ((q + S) + q) - S = 2q, each step a generic mixed addition.
+// P + (-P) needs no branch: the formula yields Z = 0 and the next addition restarts from infinity.
+//
+// WAVES = minimum waves per SIMD the register allocation must allow (1: up to 512 VGPR+AGPR,
+// 2: up to 256); selected at run time (GH_ACC_WAVES) for A/B measurements.
+template <class C, int WAVES>
+__global__ void __launch_bounds__(256, WAVES)
 msm_accumulate_kernel(const Aff<C>* __restrict__ bases, const uint32_t* __restrict__ sorted,
                       const uint32_t* __restrict__ starts, const uint32_t* __restrict__ counts,
-                      const uint32_t* __restrict__ order, uint32_t first, uint32_t total, Proj<C>* __restrict__ buckets) {
+                      const uint32_t* __restrict__ order, uint32_t first, uint32_t total,
+                      const Aff<C>* __restrict__ salts, Proj<C>* __restrict__ buckets) {
     typedef typename C::F F;
     uint32_t t = first + blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total) return;
     const uint32_t g = order[t];
     const uint32_t beg = starts[g], cnt = counts[g];
     Proj<C> acc = proj_zero<C>();
-    for (uint32_t k = 0; k < cnt; k++) {
-        const uint32_t e = sorted[beg + k];
-        Aff<C> q = ld_aff<C>(bases + (e & 0x7FFFFFFFu));
-        if (e >> 31) q.y = F::neg(q.y);
-        acc = proj_madd<C>(acc, q);
+    uint32_t k = 0;
+    int phase = 0, salt_id = 0;     // phase 0: list entry k; 1: +S; 2: entry k again; 3: -S
+    uint32_t guard = 0;
+    while (k < cnt && guard < 4 * cnt + 8) {
+        guard++;
+        Aff<C> q;
+        if (phase == 1 || phase == 3) {
+            q = ld_aff<C>(salts + salt_id);
+            if (phase == 3) q.y = F::neg(q.y);
+        } else {
+            const uint32_t e = sorted[beg + k];
+            q = ld_aff<C>(bases + (e & 0x7FFFFFFFu));
+            if (e >> 31) q.y = F::neg(q.y);
+        }
+        if (proj_is_zero<C>(acc)) {
+            acc.x = q.x; acc.y = q.y; acc.z = F::one();
+        } else {
+            // madd-1998-cmo (swp.rs:497-517)
+            typename F::T v = F::mul(q.x, acc.z);
+            typename F::T u = F::mul(q.y, acc.z);
+            if (phase == 0 && F::eq(u, acc.y) && F::eq(v, acc.x)) {   // acc == q: take the detour
+                salt_id = F::eq(q.x, ld_aff<C>(salts).x) ? 1 : 0;
+                phase = 1;
+                continue;
+            }
+            u = F::sub(u, acc.y);
+            typename F::T uu = F::sqr(u);
+            v = F::sub(v, acc.x);
+            typename F::T vv = F::sqr(v);
+            typename F::T vvv = F::mul(v, vv);
+            typename F::T r = F::mul(vv, acc.x);
+            typename F::T a = F::sub(F::sub(F::mul(uu, acc.z), vvv), F::dbl(r));
+            acc.x = F::mul(v, a);
+            acc.y = F::sub(F::mul(u, F::sub(r, a)), F::mul(vvv, acc.y));
+            acc.z = F::mul(vvv, acc.z);
+        }
+        if (phase == 0 || phase == 3) { k++; phase = 0; } else phase++;
     }
     st_proj<C>(buckets + g, acc);
 }
@@ -182,18 +255,27 @@ __device__ __forceinline__ Proj<C> wave_tree_sum(Proj<C> v, Proj<C>* sh, int lan
     return v;
 }
 
-// one wave (block of 64) per heavy bucket
+// Heavy buckets (skewed scalars; the top window, whose digits are only 0/1/2): every chunk of
+// MSM_HEAVY_CHUNK entries is summed by one wave (lanes stride through the chunk, then a tree
+// through LDS); a second launch adds the chunk sums of each heavy bucket the same way.
 template <class C>
 __global__ void __launch_bounds__(64)
-msm_heavy_kernel(const Aff<C>* __restrict__ bases, const uint32_t* __restrict__ sorted,
-                 const uint32_t* __restrict__ starts, const uint32_t* __restrict__ counts,
-                 const uint32_t* __restrict__ order, Proj<C>* __restrict__ buckets) {
+msm_heavy_chunk_kernel(const Aff<C>* __restrict__ bases, const uint32_t* __restrict__ sorted,
+                       const uint32_t* __restrict__ starts, const uint32_t* __restrict__ counts,
+                       const uint32_t* __restrict__ order, const uint32_t* __restrict__ chunk_start, uint32_t n_heavy,
+                       Proj<C>* __restrict__ partials) {
     typedef typename C::F F;
     extern __shared__ uint32_t lds_raw[];
     Proj<C>* sh = reinterpret_cast<Proj<C>*>(lds_raw);
-    const uint32_t g = order[blockIdx.x];
-    const uint32_t beg = starts[g], cnt = counts[g];
     const int lane = threadIdx.x;
+    // binary search: largest h with chunk_start[h] <= blockIdx.x
+    uint32_t lo = 0, hi = n_heavy;
+    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (chunk_start[mid] <= blockIdx.x) lo = mid; else hi = mid; }
+    const uint32_t g = order[lo];
+    const uint32_t j = blockIdx.x - chunk_start[lo];
+    const uint32_t beg = starts[g] + j * MSM_HEAVY_CHUNK;
+    uint32_t cnt = counts[g] - j * MSM_HEAVY_CHUNK;
+    if (cnt > (uint32_t)MSM_HEAVY_CHUNK) cnt = MSM_HEAVY_CHUNK;
     Proj<C> acc = proj_zero<C>();
     for (uint32_t k = lane; k < cnt; k += 64) {
         const uint32_t e = sorted[beg + k];
@@ -202,7 +284,21 @@ msm_heavy_kernel(const Aff<C>* __restrict__ bases, const uint32_t* __restrict__ 
         acc = proj_madd_call<C>(acc, q);
     }
     acc = wave_tree_sum<C>(acc, sh, lane);
-    if (lane == 0) st_proj<C>(buckets + g, acc);
+    if (lane == 0) st_proj<C>(partials + blockIdx.x, acc);
+}
+template <class C>
+__global__ void __launch_bounds__(64)
+msm_heavy_combine_kernel(const Proj<C>* __restrict__ partials, const uint32_t* __restrict__ order,
+                         const uint32_t* __restrict__ chunk_start, Proj<C>* __restrict__ buckets) {
+    extern __shared__ uint32_t lds_raw[];
+    Proj<C>* sh = reinterpret_cast<Proj<C>*>(lds_raw);
+    const int lane = threadIdx.x;
+    const uint32_t h = blockIdx.x;
+    const uint32_t beg = chunk_start[h], end = chunk_start[h + 1];
+    Proj<C> acc = proj_zero<C>();
+    for (uint32_t k = beg + lane; k < end; k += 64) acc = proj_add_call<C>(acc, ld_proj<C>(partials + k));
+    acc = wave_tree_sum<C>(acc, sh, lane);
+    if (lane == 0) st_proj<C>(buckets + order[h], acc);
 }
 
 // ---------------------------------------------------------------- 5. bucket reduction

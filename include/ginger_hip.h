@@ -106,13 +106,15 @@ int gh_msm_get_window(gh_curve_t curve, size_t n);
  * library stream, host fold by a host clock).  Any pointer may be NULL. */
 typedef struct {
     float sort_ms;        /* digit extraction + bucket sort */
-    float accumulate_ms;  /* bucket accumulation kernel (dominant) */
+    float accumulate_ms;  /* msm_accumulate_kernel alone (dominant kernel), HIP events around the launch */
+    float heavy_ms;       /* wave-cooperative path for over-long buckets */
     float reduce_ms;      /* bucket running-sum reduction kernels */
     float fold_ms;        /* window fold (host) + D2H of window sums */
     float total_ms;
     int window_bits;
     int num_windows;
-    unsigned long long accumulate_madds; /* mixed additions issued by the accumulate kernel */
+    unsigned long long accumulate_madds; /* mixed additions issued (all buckets) */
+    unsigned int heavy_buckets;
 } gh_msm_timing_t;
 int gh_msm_last_timing(gh_msm_timing_t* out);
 

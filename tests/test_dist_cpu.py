@@ -1,0 +1,65 @@
+"""The N > 1 path of the MSM (shard, local sum, all-gather of partials, fold) on two CPU ranks
+over gloo.  The local per-shard MSM is the CPU oracle here (no GPU in this container); the
+exchange and the fold (gh_proj_add from the product library, host side) are the real code."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, curve, n, ret):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    import pyref
+    import support as S
+    from __graft_entry__ import _load_pkg
+    gl = _load_pkg()
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    C = pyref.CURVES[curve]
+    rng = pyref.Rng(1234)                      # same inputs on every rank
+    pts = S.chain_points(C, n, rng)
+    scal = [rng.field_elem(C.order) for _ in range(n)]
+    b, inf = S.bases_array(C, pts)
+    s = S.scalar_array(scal)
+    sys.path.insert(0, os.path.join(ROOT, "ginger-lib_amd"))
+    import importlib
+    distmod = importlib.import_module("ginger_lib_amd.dist")
+    lo, hi = distmod.shard_bounds(n, rank, world)
+    sharded = distmod.ShardedMSM(curve, lambda sc: S.oracle_msm(curve, b[lo:hi], inf[lo:hi], sc, 2),
+                                 lambda acc, p: gl.proj_add(curve, acc, p))
+    total = sharded.multi_scalar_mul(s[lo:hi])
+    xy, is_inf = gl.proj_to_affine(curve, total)
+    full = S.oracle_msm(curve, b, inf, s, 2)
+    exy, einf = S.oracle_affine(curve, full)
+    ok = (is_inf == einf) and bool((xy == exy).all())
+    ret[rank] = ok
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("curve,n", [("mnt4753_g1", 37), ("mnt6753_g2", 9)])
+def test_two_rank_sharded_msm(curve, n):
+    world = 2
+    port = 29500 + (os.getpid() % 2000)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, curve, n, ret), nprocs=world, join=True)
+    assert all(ret[r] for r in range(world))
+
+
+def test_shard_bounds_cover():
+    sys.path.insert(0, ROOT)
+    from __graft_entry__ import _load_pkg
+    _load_pkg()
+    import importlib
+    distmod = importlib.import_module("ginger_lib_amd.dist")
+    for n in (0, 1, 7, 8, 1000):
+        for world in (1, 2, 3, 8):
+            cuts = [distmod.shard_bounds(n, r, world) for r in range(world)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == n
+            assert all(cuts[i][1] == cuts[i + 1][0] for i in range(world - 1))
+            assert max(h - l for l, h in cuts) - min(h - l for l, h in cuts) <= 1

@@ -1,0 +1,237 @@
+"""Parity tests proper: the HIP path (through the C ABI) against the CPU oracle on the same seeded
+inputs, against the committed golden fixtures, and -- at BASELINE.json's full sizes -- through
+size-independent properties (round trips, linearity, window-size invariance).
+Bit-exact: FFT outputs limb for limb; MSM after into_affine()."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import pyref
+import support as S
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+MSM_G = json.load(open(os.path.join(G, "msm_golden.json")))
+NTT_G = json.load(open(os.path.join(G, "ntt_golden.json")))
+FLAGS = (("fft", 0), ("ifft", 1), ("coset_fft", 2), ("coset_ifft", 3))
+
+
+def affine_eq(gl, curve, got_xyz, exp_xyz):
+    g_xy, g_inf = gl.proj_to_affine(curve, got_xyz)
+    e_xy, e_inf = S.oracle_affine(curve, exp_xyz)
+    return g_inf == e_inf and bool((g_xy == e_xy).all())
+
+
+# ------------------------------------------------------------------------------ NTT
+@pytest.mark.parametrize("name", list(NTT_G))
+def test_ntt_golden(gpu, name):
+    case = NTT_G[name]
+    F = S.FIELD_OF[case["field"]]
+    a = S.fe_array(F, [int(x, 16) for x in case["input"]])
+    dom = gpu.EvaluationDomain(case["field"], 1 << case["log_n"])
+    for nm, _ in FLAGS:
+        assert S.fe_list(F, getattr(dom, nm)(a)) == [int(x, 16) for x in case[nm]], (name, nm)
+
+
+@pytest.mark.parametrize("field,log_n", [("mnt4753_fr", l) for l in (0, 1, 2, 3, 4, 7, 8, 9, 10, 11, 13, 16)] +
+                         [("mnt6753_fr", l) for l in (1, 6, 12, 14)])
+def test_ntt_vs_oracle(gpu, field, log_n):
+    n = 1 << log_n
+    F = S.FIELD_OF[field]
+    for n_in in sorted({n, max(1, n - 3), n + 5}):          # exact, zero-padded, truncated (domain.rs:121)
+        a = S.random_scalars_np(n_in, seed=log_n * 7 + n_in % 5, below=F.p)
+        dom = gpu.EvaluationDomain(field, n)
+        assert dom.size == n
+        for nm, flags in FLAGS:
+            got = getattr(dom, nm)(a).reshape(-1, 12)
+            exp = S.oracle_fft(field, a, log_n, flags, 16)
+            assert (got == exp).all(), (field, log_n, n_in, nm)
+
+
+def test_domain_limits(gpu):
+    assert gpu.EvaluationDomain.new("mnt4753_fr", 1 << 30) is None          # 2-adicity 30 (domain.rs:69-71)
+    assert gpu.EvaluationDomain.new("mnt6753_fr", (1 << 14) + 1) is None    # 2-adicity 15
+    assert gpu.EvaluationDomain.new("mnt6753_fr", 1 << 14).size == 1 << 14
+    assert gpu.EvaluationDomain.new("mnt4753_fr", 0).size == 1
+
+
+def test_ntt_full_size_roundtrips(gpu):
+    """BASELINE config 2 size (2^20): ifft(fft(x)) = x and coset_ifft(coset_fft(x)) = x, device resident."""
+    log_n = 20
+    n = 1 << log_n
+    a = S.random_scalars_np(n, seed=3, below=pyref.P6.p)
+    dom = gpu.EvaluationDomain("mnt4753_fr", n)
+    buf = gpu.DeviceBuffer(n * 96).upload(a)
+    for fwd, inv in ((0, 1), (2, 3)):
+        dom.fft_dev(buf, fwd)
+        mid = buf.download().reshape(n, 12)
+        assert not (mid == a).all()
+        dom.fft_dev(buf, inv)
+        assert (buf.download().reshape(n, 12) == a).all()
+    buf.free()
+    # spot-check the forward transform itself against the oracle at 2^18
+    log_n = 18
+    n = 1 << log_n
+    a = S.random_scalars_np(n, seed=4, below=pyref.P6.p)
+    got = gpu.EvaluationDomain("mnt4753_fr", n).coset_fft(a).reshape(n, 12)
+    assert (got == S.oracle_fft("mnt4753_fr", a, log_n, 2, 16)).all()
+
+
+def test_vec_ops(gpu):
+    F = pyref.P6
+    n = 1000
+    a = S.random_scalars_np(n, seed=8, below=F.p)
+    b = S.random_scalars_np(n, seed=9, below=F.p)
+    dom = gpu.EvaluationDomain("mnt4753_fr", 1024)
+    got = dom.mul_polynomials_in_evaluation_domain(a, b).reshape(n, 12)
+    exp = a.copy()
+    S.oracle().oracle_vec_mul(0, S.ptr(exp), S.ptr(b), n)
+    assert (got == exp).all()
+    # divide_by_vanishing_poly_on_coset: multiply by (g^N - 1)^-1  (domain.rs:245-256)
+    inv = np.zeros(12, dtype=np.uint64)
+    S.oracle().oracle_vanishing_inv_on_coset(0, 10, S.ptr(inv))
+    got = gpu.vec_scale("mnt4753_fr", a, inv).reshape(n, 12)
+    bb = np.tile(inv, (n, 1))
+    exp = a.copy()
+    S.oracle().oracle_vec_mul(0, S.ptr(exp), S.ptr(bb), n)
+    assert (got == exp).all()
+
+
+# ------------------------------------------------------------------------------ MSM
+def load_msm_case(name):
+    case = MSM_G[name]
+    curve = name.replace("_zero_sum", "")
+    C = pyref.CURVES[curve]
+    pts = [None if b is None else (tuple(int(c, 16) for c in b[0]), tuple(int(c, 16) for c in b[1])) for b in case["bases"]]
+    scal = [int(s, 16) for s in case["scalars"]]
+    e = case["expected_affine"]
+    exp = None if e is None else (tuple(int(c, 16) for c in e[0]), tuple(int(c, 16) for c in e[1]))
+    return curve, C, pts, scal, exp
+
+
+@pytest.mark.parametrize("name", list(MSM_G))
+def test_msm_golden(gpu, name):
+    curve, C, pts, scal, exp = load_msm_case(name)
+    b, inf = S.bases_array(C, pts)
+    out = gpu.VariableBaseMSM.multi_scalar_mul(curve, b, S.scalar_array(scal), inf)
+    assert S.affine_of_xyz(C, out) == exp
+    xy, is_inf = gpu.proj_to_affine(curve, out)
+    assert is_inf == (exp is None)
+
+
+@pytest.mark.parametrize("curve,sizes", [("mnt4753_g1", (0, 1, 2, 31, 32, 33, 200, 3000)), ("mnt6753_g1", (1, 40, 1000)),
+                                         ("mnt4753_g2", (1, 35, 300)), ("mnt6753_g2", (2, 33, 200))])
+def test_msm_vs_oracle(gpu, curve, sizes):
+    C = pyref.CURVES[curve]
+    r = C.order
+    rng = pyref.Rng(sum(map(ord, curve)))
+    base_pool = S.chain_points(C, min(max(sizes), 512), rng)
+    for n in sizes:
+        pts = [base_pool[i % len(base_pool)] for i in range(n)]
+        scal = [rng.field_elem(r) for _ in range(n)]
+        if n >= 31:
+            scal[0], scal[1], scal[2], scal[3] = 0, 1, r - 1, 1 << 300
+            scal[4] = scal[5]
+            pts[6] = None
+            pts[8] = pts[7]; scal[8] = scal[7]
+            pts[10] = C.neg(pts[9]); scal[10] = scal[9]
+        b, inf = S.bases_array(C, pts)
+        s = S.scalar_array(scal)
+        got = gpu.VariableBaseMSM.multi_scalar_mul(curve, b, s, inf)
+        exp = S.oracle_msm(curve, b, inf, s, 16)
+        assert affine_eq(gpu, curve, got, exp), (curve, n)
+        if n == 0:
+            k = C.deg      # empty input -> (0, 1, 0)  (variable_base.rs + swp.rs:372-378)
+            assert pyref.ext_from_abi(C.F, [int(v) for v in got[12 * k:24 * k]], k) == C.E.one()
+            assert not got[24 * k:].any()
+
+
+def test_msm_unequal_lengths_and_resident(gpu):
+    curve = "mnt4753_g1"
+    C = pyref.CURVES[curve]
+    rng = pyref.Rng(77)
+    pts = S.chain_points(C, 120, rng)
+    scal = [rng.field_elem(C.order) for _ in range(150)]
+    b, inf = S.bases_array(C, pts)
+    s = S.scalar_array(scal)
+    exp = S.oracle_msm(curve, b, inf, s, 8)                     # zip truncates to 120 (variable_base.rs:36)
+    assert affine_eq(gpu, curve, gpu.VariableBaseMSM.multi_scalar_mul(curve, b, s, inf), exp)
+    exp2 = S.oracle_msm(curve, b, inf, s[:70], 8)
+    assert affine_eq(gpu, curve, gpu.VariableBaseMSM.multi_scalar_mul(curve, b, s[:70], inf), exp2)
+    rb = gpu.ResidentBases(curve, b, inf)
+    assert affine_eq(gpu, curve, rb.msm(s), exp)
+    assert affine_eq(gpu, curve, rb.msm(s[:70]), exp2)
+    ds = gpu.DeviceBuffer(s.nbytes).upload(s)
+    assert affine_eq(gpu, curve, rb.msm_dev(ds, 150), exp)
+    ds.free()
+    rb.free()
+
+
+def test_msm_skewed_scalars(gpu):
+    """Witness-like scalars: mostly 0 / 1 / small / repeated values -> a few very long buckets
+    (wave-cooperative heavy-bucket path) and the scalar == 1 shortcut of variable_base.rs:37-41."""
+    curve = "mnt4753_g1"
+    C = pyref.CURVES[curve]
+    rng = pyref.Rng(5)
+    pool = S.chain_points(C, 256, rng)
+    n = 6000
+    pts = [pool[(i * 7) % 256] for i in range(n)]
+    big = rng.field_elem(C.order)
+    scal = []
+    for i in range(n):
+        m = i % 10
+        scal.append(1 if m < 5 else 0 if m == 5 else 2 if m == 6 else big if m == 7 else (i * 12345) % 65536 if m == 8 else rng.field_elem(C.order))
+    b, inf = S.bases_array(C, pts)
+    s = S.scalar_array(scal)
+    got = gpu.VariableBaseMSM.multi_scalar_mul(curve, b, s, inf)
+    assert affine_eq(gpu, curve, got, S.oracle_msm(curve, b, inf, s, 16))
+
+
+def test_msm_full_size_properties(gpu):
+    """BASELINE config 3 size (2^20 pairs): linearity msm(s) + msm(t) == msm(s + t mod r) and
+    invariance of the affine result under the window size; spot check vs the oracle at 2^14."""
+    curve = "mnt4753_g1"
+    C = pyref.CURVES[curve]
+    r = C.order
+    rng = pyref.Rng(2020)
+    pool = S.chain_points(C, 4096, rng)
+    pb, _ = S.bases_array(C, pool)
+    n = 1 << 20
+    bases = np.tile(pb, (n // 4096, 1))
+    s = S.random_scalars_np(n, seed=11, below=r)
+    t = S.random_scalars_np(n, seed=12, below=r)
+    # (s + t) mod r, vectorised on Python ints per row would be slow: do limb arithmetic with object ints in chunks
+    def add_mod(a, b):
+        out = np.empty_like(a)
+        av = a.astype(object)
+        bv = b.astype(object)
+        for i in range(0, len(a), 1 << 16):
+            xs = [(pyref.limbs_to_int(x) + pyref.limbs_to_int(y)) % r for x, y in zip(av[i:i + (1 << 16)], bv[i:i + (1 << 16)])]
+            out[i:i + (1 << 16)] = np.array([pyref.int_to_limbs(x) for x in xs], dtype=np.uint64)
+        return out
+    m = 1 << 17                                                    # the ints loop is the slow part: use a 2^17 slice for s+t
+    st = add_mod(s[:m], t[:m])
+    rb = gpu.ResidentBases(curve, bases)
+    full_s = rb.msm(s)                                             # full 2^20 run (also timing sanity)
+    tm = gpu.msm_last_timing()
+    assert tm["accumulate_madds"] > 0.9 * n * tm["num_windows"] * 0.9
+    ms, mt, mst = rb.msm(s[:m]), rb.msm(t[:m]), rb.msm(st)
+    lhs = gpu.proj_add(curve, ms, mt)
+    a1, i1 = gpu.proj_to_affine(curve, lhs)
+    a2, i2 = gpu.proj_to_affine(curve, mst)
+    assert i1 == i2 and (a1 == a2).all()
+    # window-size invariance on the full input
+    ref_xy, ref_inf = gpu.proj_to_affine(curve, full_s)
+    for c in (13, 18):
+        gpu.msm_set_window(c)
+        xy, inf = gpu.proj_to_affine(curve, rb.msm(s))
+        assert gpu.msm_last_timing()["window_bits"] == c
+        assert inf == ref_inf and (xy == ref_xy).all()
+    gpu.msm_set_window(0)
+    # oracle spot check at 2^14 pairs
+    k = 1 << 14
+    exp = S.oracle_msm(curve, bases[:k], None, s[:k], 16)
+    assert affine_eq(gpu, curve, rb.msm(s[:k]), exp)
+    rb.free()
