@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the hot path on MI355X.
+
+Metric (BASELINE.json): "MNT4-753 G1 MSM scalar-muls/sec + 2^n NTT ms at 1/2/4/8 MI355X".
+  value  = whole-job MSM throughput: every rank runs one complete MNT4-753 G1 MSM of 2^log_n
+           (base, scalar) pairs per step on its own GPU (bases and scalars already resident in
+           HBM), then the partial sums are all-gathered and folded (weak scaling, one exchange).
+  ntt    = (extra object) 2^ntt_log_n-point MNT4-753 Fr NTT, device resident, ms per transform.
+One "step" = one pass of the MSM hot path over one batch of synthetic input.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 measured)
+FPMUL_PEAK_PER_S = 23.4e9       # measured 753-bit Montgomery products/s, profiles/r01_microbench_valu_rates.txt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--log-n", type=int, default=20, help="log2 of MSM pairs per GPU")
+    ap.add_argument("--ntt-log-n", type=int, default=24)
+    ap.add_argument("--window", type=int, default=0, help="MSM window override (0 = auto)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ntt", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    device = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
+        dist.init_process_group("nccl", device_id=device)
+
+    import pyref
+    from __graft_entry__ import _load_pkg
+    gl = _load_pkg()
+    import importlib
+    distmod = importlib.import_module("ginger_lib_amd.dist")
+    gl.init(local_rank)          # raises if the HIP library or a gfx950 device is missing: no fallback
+    if args.window:
+        gl.msm_set_window(args.window)
+
+    curve = "mnt4753_g1"
+    C = pyref.CURVES[curve]
+    n = 1 << args.log_n
+    # ---- synthetic inputs: distinct curve points along an addition chain (cofactor 1), tiled to n;
+    #      scalars uniform in [0, r) with the reference's sampling shape, different per rank.
+    pool_n = min(n, 1 << 12)
+    import support as S     # helpers only (layout conversion); the oracle is used in cpu_baseline alone
+    pool = S.chain_points(C, pool_n, pyref.Rng(1))
+    pb, _ = S.bases_array(C, pool)
+    bases = np.tile(pb, (n // pool_n, 1))
+    scalars = S.random_scalars_np(n, seed=1000 + rank, below=C.order)
+    rb = gl.ResidentBases(curve, bases)
+    ds = gl.DeviceBuffer(n * 96).upload(scalars)
+
+    def proj_add(acc, p):
+        return gl.proj_add(curve, acc, p)
+
+    def step():
+        partial = rb.msm_dev(ds, n)
+        tm = gl.msm_last_timing()
+        if world > 1:
+            total = distmod.all_gather_fold(partial, proj_add, dist=dist, device=device)
+        else:
+            total = partial
+        return total, tm
+
+    def sync():
+        load = gl.load_library()
+        load.gh_dev_sync()
+        if world > 1:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    acc_ms = []
+    phases = {"sort_ms": 0.0, "accumulate_ms": 0.0, "heavy_ms": 0.0, "reduce_ms": 0.0, "fold_ms": 0.0}
+    result = None
+    for _ in range(args.steps):
+        result, tm = step()
+        acc_ms.append(tm["accumulate_ms"])
+        for k in phases:
+            phases[k] += tm[k] / args.steps
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    value = world * n * args.steps / elapsed
+    tm_last = tm
+    acc_avg_ms = float(np.mean(acc_ms))
+    alg_bytes = 288.0 * n                      # 288 B per G1 pair (192 B base + 96 B scalar), read once
+    achieved = alg_bytes / (acc_avg_ms * 1e-3) / 1e9
+    madds = tm_last["accumulate_madds"]
+    fpmul_rate = madds * 11 / (acc_avg_ms * 1e-3)
+
+    out = {
+        "metric": "MNT4-753 G1 MSM scalar-muls/sec + 2^n NTT ms at 1/2/4/8 MI355X",
+        "value": value,
+        "unit": "scalar-muls/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u32 (29-bit limbs of 753-bit Montgomery residues, 64-bit accumulators)",
+        "data": "synthetic",
+        "config": {"workload": "MNT4-753 G1 VariableBaseMSM, 2^%d (base,scalar) pairs per GPU, bases+scalars resident in HBM" % args.log_n,
+                   "pairs_per_gpu": n, "window_bits": tm_last["window_bits"], "num_windows": tm_last["num_windows"],
+                   "distinct_bases": pool_n, "parallelism": "pairs sharded by rank, 1 all-gather of partial sums" if world > 1 else "single GPU"},
+        "roofline": {"kernel": "msm_accumulate_kernel<Mnt4G1>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "avg_launch_ms": acc_avg_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                     "note": "integer-VALU bound by construction (SURVEY 8d): see valu"},
+        "valu": {"achieved_fpmul_per_s": fpmul_rate, "peak_fpmul_per_s": FPMUL_PEAK_PER_S, "frac": fpmul_rate / FPMUL_PEAK_PER_S,
+                 "note": "11 Fp-mul per mixed addition; peak = measured rr29 Montgomery-product microbenchmark"},
+        "phases_ms": phases,
+    }
+
+    # ---- NTT (single GPU per rank; reported from rank 0)
+    if not args.no_ntt and rank == 0:
+        N = 1 << args.ntt_log_n
+        a = S.random_scalars_np(N, seed=7, below=pyref.P6.p)
+        buf = gl.DeviceBuffer(N * 96).upload(a)
+        dom = gl.EvaluationDomain("mnt4753_fr", N)
+        for _ in range(max(1, args.warmup)):
+            dom.fft_dev(buf, 0)
+        ks, walls = [], []
+        for i in range(max(3, args.steps)):
+            t1 = time.perf_counter()
+            dom.fft_dev(buf, i & 3)          # cycle fft / ifft / coset_fft / coset_ifft
+            walls.append((time.perf_counter() - t1) * 1e3)
+            ks.append(gl.fft_last_kernel_ms())
+        buf.free()
+        ntt_ms = float(np.mean(ks))
+        nb = 2.0 * N * 96
+        out["ntt"] = {"field": "MNT4-753 Fr", "log_n": args.ntt_log_n, "ms": ntt_ms, "wall_ms": float(np.mean(walls)),
+                      "transforms": "fft, ifft, coset_fft, coset_ifft cycled; device resident, in place",
+                      "roofline": {"kernel": "ntt_pass_kernel<P6> (all passes of one transform)", "bound": "hbm",
+                                   "achieved": nb / (ntt_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": nb / (ntt_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                   "algorithmic_bytes_per_transform": nb}}
+
+    # ---- CPU baseline: the oracle (restated reference algorithm, C++) on the host cores, bounded sample
+    if not args.no_cpu_baseline and rank == 0 and world == 1:
+        cores = os.cpu_count() or 1
+        m = min(n, 1 << 16)        # BASELINE configs[0]: 2^16 pairs on the CPU path
+        import math
+        c_ref = 3 if m < 32 else math.ceil(2.0 / 3.0 * math.log2(m) + 2.0)      # variable_base.rs:14-18
+        msm_threads = min(cores, -(-753 // c_ref))                               # one task per window (:30-31)
+        t1 = time.perf_counter()
+        exp = S.oracle_msm(curve, bases[:m], None, scalars[:m], msm_threads)
+        cpu_s = time.perf_counter() - t1
+        got = rb.msm(scalars[:m])
+        g_xy, g_inf = gl.proj_to_affine(curve, got)
+        e_xy, e_inf = S.oracle_affine(curve, exp)
+        parity = bool(g_inf == e_inf and (g_xy == e_xy).all())
+        out["cpu_baseline"] = {"value": m / cpu_s, "unit": "scalar-muls/s", "cores": msm_threads, "host_cores": cores, "kind": "port",
+                               "sample": "oracle (C++ restatement of variable_base.rs:10-83, window-parallel) on the first 2^%d pairs of the same inputs, %.2f s" % (int(np.log2(m)), cpu_s),
+                               "gpu_matches_oracle_on_sample": parity}
+        if not parity:
+            out["error"] = "GPU result differs from the oracle on the CPU-baseline sample"
+        if "ntt" in out:
+            ln = min(args.ntt_log_n, 20)
+            a = S.random_scalars_np(1 << ln, seed=8, below=pyref.P6.p)
+            t1 = time.perf_counter()
+            fft_threads = min(cores, 32)     # best_fft splits into 2^floor(log2 threads) sub-FFTs and its O(n*P) gather grows with P
+            ref = S.oracle_fft("mnt4753_fr", a, ln, 0, fft_threads)
+            cpu_ms = (time.perf_counter() - t1) * 1e3
+            got = gl.EvaluationDomain("mnt4753_fr", 1 << ln).fft(a).reshape(-1, 12)
+            out["ntt"]["cpu_baseline"] = {"log_n": ln, "ms": cpu_ms, "cores": fft_threads, "host_cores": cores, "kind": "port",
+                                          "sample": "oracle best_fft (domain.rs:305-416) at 2^%d" % ln,
+                                          "gpu_ms_same_size": gl.fft_last_kernel_ms(),
+                                          "gpu_matches_oracle_on_sample": bool((got == ref).all())}
+    rb.free()
+    ds.free()
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+    if out.get("error"):
+        sys.exit(1)
+
+
+if __name__ == "__main__":
+    main()

@@ -76,6 +76,31 @@ __global__ void __launch_bounds__(256) msm_convert_bases_kernel(const uint32_t* 
     for (int w = 0; w < (int)(sizeof(Aff<C>) / 8); w++) q[w] = s[w];
 }
 
+// Wave-aggregated counter increment: returns the old value of base[key] as if every active lane
+// had done atomicAdd(base + key, 1).  Up to `iters` distinct keys are combined into one atomic
+// each (leader election by ballot); the rest fall back to per-lane atomics.  Random digits pay a
+// few ballots; skewed digits (the top window holds only 0/1/2, witnesses are full of 0/1) no
+// longer serialise a million atomics on one address.  Must be called by all 64 lanes of the wave.
+static __device__ __forceinline__ uint32_t wave_agg_inc(uint32_t* base, uint32_t key, bool active, int iters) {
+    const int lane = threadIdx.x & 63;
+    unsigned long long todo = __ballot(active);
+    uint32_t result = 0;
+    bool done = !active;
+    for (int it = 0; it < iters && todo; it++) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t lkey = __shfl(key, leader);
+        const bool mine = !done && key == lkey;
+        const unsigned long long same = __ballot(mine);
+        uint32_t b = 0;
+        if (lane == leader) b = atomicAdd(base + lkey, (uint32_t)__popcll(same));
+        b = __shfl(b, leader);
+        if (mine) { result = b + (uint32_t)__popcll(same & ((1ull << lane) - 1ull)); done = true; }
+        todo &= ~same;
+    }
+    if (!done) result = atomicAdd(base + key, 1u);
+    return result;
+}
+
 // ---------------------------------------------------------------- 1. digits + histogram
 // scalars: n x 24 words canonical.  digits[w * n + i] = signed digit (0 = no contribution).
 // counts[w * nb + |d|] += 1, nb = 2^(c-1) + 1 (slot 0 unused).
@@ -86,13 +111,16 @@ static __global__ void __launch_bounds__(256)
 msm_digits_kernel(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ infinity, size_t n, int c,
                   int num_windows, uint32_t nb, int32_t* __restrict__ digits, uint32_t* __restrict__ counts) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    const bool valid = i < n;
     uint32_t s[25];
-    const uint4* q = reinterpret_cast<const uint4*>(scalars + i * 24);
 #pragma unroll
-    for (int k = 0; k < 6; k++) { uint4 v = q[k]; s[4 * k] = v.x; s[4 * k + 1] = v.y; s[4 * k + 2] = v.z; s[4 * k + 3] = v.w; }
-    s[24] = 0;
-    const bool skip = infinity != nullptr && infinity[i] != 0;
+    for (int k = 0; k < 25; k++) s[k] = 0;
+    if (valid) {
+        const uint4* q = reinterpret_cast<const uint4*>(scalars + i * 24);
+#pragma unroll
+        for (int k = 0; k < 6; k++) { uint4 v = q[k]; s[4 * k] = v.x; s[4 * k + 1] = v.y; s[4 * k + 2] = v.z; s[4 * k + 3] = v.w; }
+    }
+    const bool skip = !valid || (infinity != nullptr && infinity[i] != 0);
     const uint32_t half = 1u << (c - 1), full_mask = (c == 32) ? 0xFFFFFFFFu : ((1u << c) - 1);
     uint32_t carry = 0;
     for (int w = 0; w < num_windows; w++) {
@@ -107,11 +135,9 @@ msm_digits_kernel(const uint32_t* __restrict__ scalars, const uint8_t* __restric
         int32_t d;
         if (v > half) { d = (int32_t)v - (int32_t)(1u << c); carry = 1; } else { d = (int32_t)v; carry = 0; }
         if (skip) d = 0;
-        digits[(size_t)w * n + i] = d;
-        if (d != 0) {
-            uint32_t mag = d < 0 ? (uint32_t)(-d) : (uint32_t)d;
-            atomicAdd(&counts[(size_t)w * nb + mag], 1u);
-        }
+        if (valid) digits[(size_t)w * n + i] = d;
+        const uint32_t mag = d < 0 ? (uint32_t)(-d) : (uint32_t)d;
+        wave_agg_inc(counts + (size_t)w * nb, mag, d != 0, 4);
     }
 }
 
@@ -168,12 +194,10 @@ msm_scatter_kernel(const int32_t* __restrict__ digits, size_t n, int num_windows
                    uint32_t* __restrict__ cursor /* = copy of starts */, uint32_t* __restrict__ sorted) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     int w = blockIdx.y;
-    if (i >= n) return;
-    int32_t d = digits[(size_t)w * n + i];
-    if (d == 0) return;
-    uint32_t mag = d < 0 ? (uint32_t)(-d) : (uint32_t)d;
-    uint32_t pos = atomicAdd(&cursor[(size_t)w * nb + mag], 1u);
-    sorted[pos] = (uint32_t)i | (d < 0 ? 0x80000000u : 0u);
+    const int32_t d = i < n ? digits[(size_t)w * n + i] : 0;
+    const uint32_t mag = d < 0 ? (uint32_t)(-d) : (uint32_t)d;
+    const uint32_t pos = wave_agg_inc(cursor + (size_t)w * nb, mag, d != 0, 4);
+    if (d != 0) sorted[pos] = (uint32_t)i | (d < 0 ? 0x80000000u : 0u);
 }
 
 // ---------------------------------------------------------------- 4. bucket accumulation
