@@ -58,4 +58,76 @@ template <class P, int NR> struct HostInv<F3<P, NR>> {
 };
 template <class F> inline typename F::T host_inv(const typename F::T& a) { return HostInv<F>::inv(a); }
 
+// ------------------------------------------------------------------------------------------
+// Host-side field for the window fold of G1 results: 12 x u64 limbs, Montgomery radix 2^768 --
+// i.e. exactly the ABI representation -- with a plain CIOS product on unsigned __int128.  The
+// fold is ~750 dependent doublings; on the host a 64-bit-limb product costs about a third of the
+// 26 x 29-bit one.  Same static interface as F1<P>, so ec29.h's proj_dbl / proj_add apply.
+struct H64 { uint64_t l[12]; };
+template <class P> struct HostConsts;
+template <> struct HostConsts<P4> {
+    static constexpr uint64_t MOD[12] = GH_P4_P_64, ONE[12] = GH_P4_R_64;
+    static constexpr uint64_t INV = GH_P4_INV64;
+};
+template <> struct HostConsts<P6> {
+    static constexpr uint64_t MOD[12] = GH_P6_P_64, ONE[12] = GH_P6_R_64;
+    static constexpr uint64_t INV = GH_P6_INV64;
+};
+template <class P> struct HF1 {
+    typedef H64 T;
+    typedef unsigned __int128 u128;
+    typedef HostConsts<P> K;
+    static constexpr int DEG = 1;
+    static T zero() { T r; for (int i = 0; i < 12; i++) r.l[i] = 0; return r; }
+    static T one() { T r; for (int i = 0; i < 12; i++) r.l[i] = K::ONE[i]; return r; }
+    static bool is_zero(const T& a) { uint64_t o = 0; for (int i = 0; i < 12; i++) o |= a.l[i]; return o == 0; }
+    static bool eq(const T& a, const T& b) { uint64_t o = 0; for (int i = 0; i < 12; i++) o |= a.l[i] ^ b.l[i]; return o == 0; }
+    static bool geq_mod(const uint64_t* t) {
+        for (int i = 11; i >= 0; i--) { if (t[i] > K::MOD[i]) return true; if (t[i] < K::MOD[i]) return false; }
+        return true;
+    }
+    static void sub_mod(uint64_t* t) { uint64_t bw = 0; for (int i = 0; i < 12; i++) { u128 x = (u128)t[i] - K::MOD[i] - bw; t[i] = (uint64_t)x; bw = (uint64_t)(x >> 64) & 1; } }
+    static T add(const T& a, const T& b) {
+        T r; uint64_t c = 0;
+        for (int i = 0; i < 12; i++) { u128 x = (u128)a.l[i] + b.l[i] + c; r.l[i] = (uint64_t)x; c = (uint64_t)(x >> 64); }
+        if (geq_mod(r.l)) sub_mod(r.l);   // no carry out: 2p < 2^768
+        return r;
+    }
+    static T dbl(const T& a) { return add(a, a); }
+    static T sub(const T& a, const T& b) {
+        T r; uint64_t bw = 0;
+        for (int i = 0; i < 12; i++) { u128 x = (u128)a.l[i] - b.l[i] - bw; r.l[i] = (uint64_t)x; bw = (uint64_t)(x >> 64) & 1; }
+        if (bw) { uint64_t c = 0; for (int i = 0; i < 12; i++) { u128 x = (u128)r.l[i] + K::MOD[i] + c; r.l[i] = (uint64_t)x; c = (uint64_t)(x >> 64); } }
+        return r;
+    }
+    static T neg(const T& a) { return is_zero(a) ? a : sub(zero(), a); }
+    static T mul(const T& a, const T& b) {
+        uint64_t t[14];
+        for (int i = 0; i < 14; i++) t[i] = 0;
+        for (int i = 0; i < 12; i++) {
+            uint64_t c = 0;
+            for (int j = 0; j < 12; j++) { u128 x = (u128)a.l[i] * b.l[j] + t[j] + c; t[j] = (uint64_t)x; c = (uint64_t)(x >> 64); }
+            u128 y = (u128)t[12] + c; t[12] = (uint64_t)y; t[13] = (uint64_t)(y >> 64);
+            const uint64_t m = t[0] * K::INV;
+            c = (uint64_t)(((u128)m * K::MOD[0] + t[0]) >> 64);
+            for (int j = 1; j < 12; j++) { u128 x = (u128)m * K::MOD[j] + t[j] + c; t[j - 1] = (uint64_t)x; c = (uint64_t)(x >> 64); }
+            y = (u128)t[12] + c; t[11] = (uint64_t)y; t[12] = t[13] + (uint64_t)(y >> 64);
+        }
+        if (t[12] || geq_mod(t)) sub_mod(t);
+        T r; for (int i = 0; i < 12; i++) r.l[i] = t[i];
+        return r;
+    }
+    static T sqr(const T& a) { return mul(a, a); }
+    static T mul_small(const T& a, int k) {   // k * a by double-and-add
+        T acc = a; int top = 30; while (!((k >> top) & 1)) top--;
+        for (int b = top - 1; b >= 0; b--) { acc = dbl(acc); if ((k >> b) & 1) acc = add(acc, a); }
+        return acc;
+    }
+};
+struct HostMnt4G1 { typedef HF1<P4> F; typedef HF1<P4> FC; static H64 mul_by_a(const H64& z) { return HF1<P4>::dbl(z); } };
+struct HostMnt6G1 { typedef HF1<P6> F; typedef HF1<P6> FC; static H64 mul_by_a(const H64& z) { return HF1<P6>::mul_small(z, 11); } };
+template <class C> struct HostCurveOf { typedef C type; static constexpr bool fast = false; };
+template <> struct HostCurveOf<Mnt4G1> { typedef HostMnt4G1 type; static constexpr bool fast = true; };
+template <> struct HostCurveOf<Mnt6G1> { typedef HostMnt6G1 type; static constexpr bool fast = true; };
+
 }  // namespace gh

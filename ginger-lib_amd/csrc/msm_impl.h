@@ -91,6 +91,50 @@ int upload_bases(const uint64_t* bases, const uint8_t* infinity, size_t n, Bases
     return GH_OK;
 }
 
+// Horner over windows, high to low (variable_base.rs:73-82).  Per window the device delivers
+// (PW, PS, PA, PB) with  R_w = PW 2^(u+6) + PS 2^u + PA 2^6 + PB;  the terms of
+// acc * 2^c + R_w are folded by descending exponent so that the powers of two cost no doubling
+// beyond the c per window that the Horner step needs anyway.  HC is the curve policy the fold
+// runs on: the fast 64-bit-limb host field for G1, the generic rr29 code otherwise.
+template <class HC>
+Proj<HC> fold_generic(const std::vector<Proj<HC>>& hw, int W, int c, int u) {
+    auto dbl_n = [](Proj<HC> a, int k) { for (int d = 0; d < k; d++) a = proj_dbl<HC>(a); return a; };
+    Proj<HC> acc = proj_zero<HC>();
+    for (int w = W - 1; w >= 0; w--) {
+        const Proj<HC>* pts[5] = {&acc, &hw[(size_t)(0 * W + w) * 3 + 1], &hw[(size_t)(0 * W + w) * 3 + 2],
+                                  &hw[(size_t)(1 * W + w) * 3 + 0], &hw[(size_t)(2 * W + w) * 3 + 0]};
+        int ex[5] = {c, u + 6, u, 6, 0};
+        int idx[5] = {0, 1, 2, 3, 4};
+        for (int a = 1; a < 5; a++) for (int b = a; b > 0 && ex[idx[b]] > ex[idx[b - 1]]; b--) { int t = idx[b]; idx[b] = idx[b - 1]; idx[b - 1] = t; }
+        Proj<HC> val = *pts[idx[0]];
+        int cur = ex[idx[0]];
+        for (int k = 1; k < 5; k++) {
+            val = dbl_n(val, cur - ex[idx[k]]);
+            cur = ex[idx[k]];
+            val = proj_add<HC>(val, *pts[idx[k]]);
+        }
+        acc = val;
+    }
+    if (proj_is_zero<HC>(acc)) acc = proj_zero<HC>();   // canonical (0, 1, 0) like the reference's zero()
+    return acc;
+}
+
+template <class C>
+void fold_windows(const std::vector<Proj<C>>& hw, int W, int c, int u, uint64_t* out_xyz) {
+    typedef typename HostCurveOf<C>::type HC;
+    if constexpr (HostCurveOf<C>::fast) {
+        std::vector<Proj<HC>> h64(hw.size());
+        for (size_t i = 0; i < hw.size(); i++) {   // internal -> ABI Montgomery limbs == host representation
+            proj_to_abi_host<C>(reinterpret_cast<uint64_t*>(&h64[i]), hw[i]);
+        }
+        Proj<HC> acc = fold_generic<HC>(h64, W, c, u);
+        memcpy(out_xyz, &acc, sizeof(acc));
+    } else {
+        Proj<C> acc = fold_generic<C>(hw, W, c, u);
+        proj_to_abi_host<C>(out_xyz, acc);
+    }
+}
+
 template <class C>
 int msm_run(BasesBase* h, const void* d_scalars, size_t n_scalars, uint64_t* out_xyz) {
     size_t n = h->n < n_scalars ? h->n : n_scalars;
@@ -105,9 +149,12 @@ int msm_run(BasesBase* h, const void* d_scalars, size_t n_scalars, uint64_t* out
     const int W = 753 / c + 1;
     const uint32_t nb = (1u << (c - 1)) + 1;
     const size_t total = (size_t)W * nb;
-    const uint32_t seg_slots = 64 * MSM_REDUCE_L;
-    const uint32_t nbp = ((nb + seg_slots - 1) / seg_slots) * seg_slots;
-    const uint32_t segs_per_window = nbp / seg_slots;
+    static const int env_L1 = getenv("GH_REDUCE_L") ? atoi(getenv("GH_REDUCE_L")) : 0;
+    int L1 = MSM_REDUCE_L;                                         // items per lane, level 1 (power of two)
+    if (env_L1 == 4 || env_L1 == 8 || env_L1 == 16 || env_L1 == 32) L1 = env_L1;
+    const uint32_t seg_slots = 64 * (uint32_t)L1;
+    const uint32_t segs_per_window = (nb + seg_slots - 1) / seg_slots;
+    const int L2 = (int)((segs_per_window + 63) / 64);             // items per lane, level 2 (one wave per window)
     if ((size_t)W * n >= ((size_t)1 << 32) || total >= ((size_t)1 << 31)) {
         g_err = "MSM too large for 32-bit bucket offsets";
         return GH_E_UNSUPPORTED;
@@ -127,7 +174,7 @@ int msm_run(BasesBase* h, const void* d_scalars, size_t n_scalars, uint64_t* out
     const size_t max_heavy = ((size_t)W * n) / (heavy_thr + 1) + 1;          // buckets with > thr entries
     const size_t max_chunks = ((size_t)W * n) / MSM_HEAVY_CHUNK + max_heavy + 1;
     int32_t* digits; uint32_t *counts, *starts, *cursor, *sorted, *order, *size_hist, *size_cursor, *chunk_start, *plan;
-    Proj<C>*buckets, *seg_run, *seg_wacc, *wsums, *partials;
+    Proj<C>*buckets, *seg_out, *win_out, *partials;
     int rc;
 #define POOL(name, ptr, bytes) if ((rc = pool_get(name, bytes, (void**)&ptr))) return rc;
     POOL("digits", digits, (size_t)W * n * 4)
@@ -141,9 +188,8 @@ int msm_run(BasesBase* h, const void* d_scalars, size_t n_scalars, uint64_t* out
     POOL("chunk_start", chunk_start, (max_heavy + 2) * 4)
     POOL("plan", plan, 16)
     POOL("buckets", buckets, total * sizeof(Proj<C>))
-    POOL("seg_run", seg_run, (size_t)W * segs_per_window * sizeof(Proj<C>))
-    POOL("seg_wacc", seg_wacc, (size_t)W * segs_per_window * sizeof(Proj<C>))
-    POOL("wsums", wsums, (size_t)W * sizeof(Proj<C>))
+    POOL("seg_out", seg_out, (size_t)W * segs_per_window * 3 * sizeof(Proj<C>))
+    POOL("win_out", win_out, (size_t)3 * W * 3 * sizeof(Proj<C>))
 #undef POOL
     hipStream_t st = g.stream;
     static const bool dbg = getenv("GH_DEBUG") != nullptr;
@@ -209,28 +255,30 @@ int msm_run(BasesBase* h, const void* d_scalars, size_t n_scalars, uint64_t* out
     }
     HIPCHK(hipEventRecord(g.ev[4], st));
     TRACE("heavy done")
-    hipLaunchKernelGGL((msm_reduce1_kernel<C>), dim3((unsigned)(W * segs_per_window)), dim3(64), lds_wave, st,
-                       (const Proj<C>*)buckets, nb, nbp, seg_run, seg_wacc);
-    TRACE("reduce1 done")
-    int log_u = 0;
-    while ((1u << log_u) < seg_slots) log_u++;
-    hipLaunchKernelGGL((msm_reduce2_kernel<C>), dim3((unsigned)W), dim3(64), lds_wave, st, (const Proj<C>*)seg_run,
-                       (const Proj<C>*)seg_wacc, segs_per_window, log_u, wsums);
+    {   // level 1: one wave per segment of 64 * L1 bucket slots -> (runW, A, Bv) per segment
+        WaveReduceIn<C> i0{buckets, 1, 0, nb, 0}, none{nullptr, 0, 0, 0, 0};
+        hipLaunchKernelGGL((msm_wave_reduce_kernel<C>), dim3((unsigned)(W * segs_per_window)), dim3(64), lds_wave, st,
+                           i0, none, none, (uint32_t)(W * segs_per_window), segs_per_window, L1, (const Aff<C>*)salts, seg_out);
+        // level 2: one wave per window and per array: weighted program on runW, plain sums of A and Bv
+        WaveReduceIn<C> r0{seg_out, 3, 0, segs_per_window, 0}, r1{seg_out, 3, 1, segs_per_window, 1}, r2{seg_out, 3, 2, segs_per_window, 1};
+        hipLaunchKernelGGL((msm_wave_reduce_kernel<C>), dim3((unsigned)(3 * W)), dim3(64), lds_wave, st,
+                           r0, r1, r2, (uint32_t)W, 1u, L2, (const Aff<C>*)salts, win_out);
+    }
     HIPCHK(hipGetLastError());
-    TRACE("reduce2 done")
+    TRACE("reduce done")
     HIPCHK(hipEventRecord(g.ev[5], st));
-    std::vector<Proj<C>> hw(W);
-    HIPCHK(hipMemcpyAsync(hw.data(), wsums, (size_t)W * sizeof(Proj<C>), hipMemcpyDeviceToHost, st));
+    std::vector<Proj<C>> hw((size_t)9 * W);
+    HIPCHK(hipMemcpyAsync(hw.data(), win_out, hw.size() * sizeof(Proj<C>), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     auto t_fold0 = std::chrono::steady_clock::now();
-    // window fold, high to low (variable_base.rs:73-82)
-    Proj<C> acc = hw[W - 1];
-    for (int w = W - 2; w >= 0; w--) {
-        for (int d = 0; d < c; d++) acc = proj_dbl<C>(acc);
-        acc = proj_add<C>(acc, hw[w]);
-    }
-    if (proj_is_zero<C>(acc)) acc = proj_zero<C>();   // canonical (0, 1, 0) like the reference's zero()
-    proj_to_abi_host<C>(out_xyz, acc);
+    // Window sum R_w = 64 PA + PB + U (64 PW + PS), U = 64 L1 = 2^u, with
+    //   PW, PS = (A, Bv) of the weighted level-2 program over the runW's, PA = sum A, PB = sum Bv.
+    // Horner over windows, high to low (variable_base.rs:73-82), with the powers of two of R_w
+    // merged into the c doublings between windows:
+    //   acc*2^c + R_w = (((acc*2^(c-u-6) + PW)*2^6 + PS)*2^(u-6) + PA)*2^6 + PB        (c >= u + 6)
+    int u = 6;
+    while ((1 << (u - 6)) < L1) u++;
+    fold_windows<C>(hw, W, c, u, out_xyz);
     TRACE("fold done")
 #undef TRACE
     auto t_end = std::chrono::steady_clock::now();

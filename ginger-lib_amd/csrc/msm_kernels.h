@@ -30,10 +30,10 @@
 
 namespace gh {
 
-constexpr int MSM_REDUCE_L = 8;          // buckets folded serially per lane in reduce level 1
+constexpr int MSM_REDUCE_L = 16;         // buckets folded serially per lane in reduce level 1
 constexpr int MSM_MAX_HEAVY_THRESHOLD = 1024;  // upper bound of the run-time heavy threshold
 constexpr int MSM_SIZE_BINS = MSM_MAX_HEAVY_THRESHOLD + 2;
-constexpr int MSM_HEAVY_CHUNK = 256;           // entries of a heavy bucket summed by one wave
+constexpr int MSM_HEAVY_CHUNK = 512;          // entries of a heavy bucket summed by one wave
 
 // ---------------------------------------------------------------- generic point load / store
 template <class C> __device__ __forceinline__ Aff<C> ld_aff(const Aff<C>* p) {
@@ -137,7 +137,7 @@ msm_digits_kernel(const uint32_t* __restrict__ scalars, const uint8_t* __restric
         if (skip) d = 0;
         if (valid) digits[(size_t)w * n + i] = d;
         const uint32_t mag = d < 0 ? (uint32_t)(-d) : (uint32_t)d;
-        wave_agg_inc(counts + (size_t)w * nb, mag, d != 0, 4);
+        wave_agg_inc(counts + (size_t)w * nb, mag, d != 0, 12);
     }
 }
 
@@ -196,7 +196,7 @@ msm_scatter_kernel(const int32_t* __restrict__ digits, size_t n, int num_windows
     int w = blockIdx.y;
     const int32_t d = i < n ? digits[(size_t)w * n + i] : 0;
     const uint32_t mag = d < 0 ? (uint32_t)(-d) : (uint32_t)d;
-    const uint32_t pos = wave_agg_inc(cursor + (size_t)w * nb, mag, d != 0, 4);
+    const uint32_t pos = wave_agg_inc(cursor + (size_t)w * nb, mag, d != 0, 12);
     if (d != 0) sorted[pos] = (uint32_t)i | (d < 0 ? 0x80000000u : 0u);
 }
 
@@ -283,7 +283,7 @@ __device__ __forceinline__ Proj<C> wave_tree_sum(Proj<C> v, Proj<C>* sh, int lan
 // MSM_HEAVY_CHUNK entries is summed by one wave (lanes stride through the chunk, then a tree
 // through LDS); a second launch adds the chunk sums of each heavy bucket the same way.
 template <class C>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64, 2)
 msm_heavy_chunk_kernel(const Aff<C>* __restrict__ bases, const uint32_t* __restrict__ sorted,
                        const uint32_t* __restrict__ starts, const uint32_t* __restrict__ counts,
                        const uint32_t* __restrict__ order, const uint32_t* __restrict__ chunk_start, uint32_t n_heavy,
@@ -311,7 +311,7 @@ msm_heavy_chunk_kernel(const Aff<C>* __restrict__ bases, const uint32_t* __restr
     if (lane == 0) st_proj<C>(partials + blockIdx.x, acc);
 }
 template <class C>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64, 2)
 msm_heavy_combine_kernel(const Proj<C>* __restrict__ partials, const uint32_t* __restrict__ order,
                          const uint32_t* __restrict__ chunk_start, Proj<C>* __restrict__ buckets) {
     extern __shared__ uint32_t lds_raw[];
@@ -326,108 +326,151 @@ msm_heavy_combine_kernel(const Proj<C>* __restrict__ partials, const uint32_t* _
 }
 
 // ---------------------------------------------------------------- 5. bucket reduction
-// Level 1: block = one wave, covers 64 * L consecutive bucket slots of ONE window
-// (slots per window nbp = padded to a multiple of 64 * L; slot index == bucket weight).
-// Lane l folds slots [l L, l L + L): run = sum B, wacc = sum (i) B_(lL + i)  (local weights 0..L-1).
-// Wave combine: S_l = suffix sum of run;  result_w = sum_l wacc_l + L * sum_{l>=1} S_l,
-// result_run = S_0.  Output (run, wacc) per wave = per segment of 64 L slots with local weights.
-template <class C>
-__device__ __forceinline__ void wave_weighted_combine(Proj<C> run, Proj<C> wacc, int log_unit, Proj<C>* sh, int lane,
-                                                      Proj<C>& out_run, Proj<C>& out_wacc) {
-    // suffix scan of run (Hillis-Steele): S_l = sum_{j >= l} run_j
-    Proj<C> S = run;
-    for (int off = 1; off < 64; off <<= 1) {
-        st_proj<C>(sh + lane, S);
-        __syncthreads();
-        if (lane + off < 64) S = proj_add_call<C>(S, ld_proj<C>(sh + lane + off));
-        __syncthreads();
-    }
-    // V_l = wacc_l + unit * S_l (l >= 1), V_0 = wacc_0
-    Proj<C> V = wacc;
-    if (lane >= 1) {
-        Proj<C> T = S;
-        for (int d = 0; d < log_unit; d++) T = proj_dbl_call<C>(T);
-        V = proj_add_call<C>(V, T);
-    }
-    out_run = S;  // valid in lane 0
-    out_wacc = wave_tree_sum<C>(V, sh, lane);
+// sum_b b * B_b per window, without the reference's per-window inversion (variable_base.rs:60-66)
+// and without any doubling or function call on the device.
+//
+// msm_wave_reduce_kernel is a "wave program": one wave per segment of 64 * L consecutive items of
+// one window; lane l owns items l, l + 64, l + 128, ... (stride 64).  Every step of the program is
+// one projective addition issued from a SINGLE inlined call site (operands are selected per
+// step), so the kernel stays within 256 VGPRs / 2 waves per SIMD and passes nothing through
+// scratch (the earlier call-based version moved ~7 KB of scratch per addition and was
+// scratch-bandwidth bound):
+//   steps 0 .. 2L-2   serial:  run += item_i  (i = L-1 .. 0),  wacc += run      -> run_l = sum_i x,
+//                                                                                   wacc_l = sum_i i * x
+//   6 steps           tree over lanes of wacc                    -> A  = sum_l wacc_l
+//   6 steps           suffix scan over lanes of run              -> S_l = sum_{m >= l} run_m;  runW = S_0
+//   6 steps           tree over lanes l >= 1 of S                -> Bv = sum_l l * run_l
+// With item index = l + 64 i:   sum_items index * x = 64 * A + Bv,  sum_items x = runW.
+// mode 1 (plain sum) stops after the serial part and a tree over run.
+// Equal operands (acc == x as points, the reference's doubling branch) are detected in the
+// addition; the whole wave then spends three extra steps on a detour through a salt point
+// (p + S) + q - S for the affected lanes.  Powers of two (64, 64 L) that weight the outputs are
+// NOT applied here: they are folded into the host's Horner loop over the windows, where the
+// doublings are needed anyway (msm_impl.h: fold_windows).
+template <class C> struct WaveReduceIn {
+    const Proj<C>* base;   // item (w, k) = base[(w * count + k) * stride + offset]
+    uint32_t stride, offset, count, mode;
+};
+
+// branch-free projective addition with selects for the infinity cases; same = (p == q as points)
+template <class C> __device__ __forceinline__ Proj<C> proj_add_sel(const Proj<C>& p, const Proj<C>& q, bool& same) {
+    typedef typename C::F F;
+    const bool pz = F::is_zero(p.z), qz = F::is_zero(q.z);
+    typename F::T y1z2 = F::mul(p.y, q.z);
+    typename F::T x1z2 = F::mul(p.x, q.z);
+    typename F::T z1z2 = F::mul(p.z, q.z);
+    typename F::T u = F::sub(F::mul(p.z, q.y), y1z2);
+    typename F::T v = F::sub(F::mul(p.z, q.x), x1z2);
+    same = !pz && !qz && F::is_zero(u) && F::is_zero(v);
+    typename F::T uu = F::sqr(u);
+    typename F::T vv = F::sqr(v);
+    typename F::T vvv = F::mul(v, vv);
+    typename F::T r = F::mul(vv, x1z2);
+    typename F::T a = F::sub(F::sub(F::mul(uu, z1z2), vvv), F::dbl(r));
+    Proj<C> o;
+    o.x = F::mul(v, a);
+    o.y = F::sub(F::mul(F::sub(r, a), u), F::mul(vvv, y1z2));
+    o.z = F::mul(vvv, z1z2);
+    uint32_t* ow = reinterpret_cast<uint32_t*>(&o);
+    const uint32_t* pw = reinterpret_cast<const uint32_t*>(&p);
+    const uint32_t* qw = reinterpret_cast<const uint32_t*>(&q);
+#pragma unroll
+    for (int k = 0; k < (int)(sizeof(Proj<C>) / 4); k++) ow[k] = pz ? qw[k] : (qz ? pw[k] : ow[k]);
+    return o;
 }
 
 template <class C>
-__global__ void __launch_bounds__(64)
-msm_reduce1_kernel(const Proj<C>* __restrict__ buckets, uint32_t nb /* valid slots per window */, uint32_t nbp /* padded */,
-                   Proj<C>* __restrict__ seg_run, Proj<C>* __restrict__ seg_wacc) {
+__global__ void __launch_bounds__(64, 2)
+msm_wave_reduce_kernel(WaveReduceIn<C> in0, WaveReduceIn<C> in1, WaveReduceIn<C> in2, uint32_t blocks_per_input,
+                       uint32_t segs_per_window, int L, const Aff<C>* __restrict__ salts, Proj<C>* __restrict__ out) {
+    typedef typename C::F F;
     extern __shared__ uint32_t lds_raw[];
     Proj<C>* sh = reinterpret_cast<Proj<C>*>(lds_raw);
     const int lane = threadIdx.x;
-    const uint32_t segs_per_window = nbp / (64 * MSM_REDUCE_L);
-    const uint32_t w = blockIdx.x / segs_per_window, seg = blockIdx.x % segs_per_window;
-    const uint32_t slot0 = seg * 64 * MSM_REDUCE_L + lane * MSM_REDUCE_L;
-    Proj<C> run = proj_zero<C>(), wacc = proj_zero<C>();
-    // descending: run accumulates suffixes, wacc += run after each step gives local weights 0..L-1
-    for (int i = MSM_REDUCE_L - 1; i >= 0; i--) {
-        const uint32_t slot = slot0 + i;
-        if (slot < nb && slot > 0) run = proj_add_call<C>(run, ld_proj<C>(buckets + (size_t)w * nb + slot));
-        if (i > 0) wacc = proj_add_call<C>(wacc, run);
-    }
-    Proj<C> orun, owacc;
-    int log_unit = 0;
-    while ((1 << log_unit) < MSM_REDUCE_L) log_unit++;
-    wave_weighted_combine<C>(run, wacc, log_unit, sh, lane, orun, owacc);
-    if (lane == 0) {
-        st_proj<C>(seg_run + blockIdx.x, orun);
-        st_proj<C>(seg_wacc + blockIdx.x, owacc);
-    }
-}
-
-// Level 2: one wave per window combines its segments (segs_per_window <= 64 * LSEG handled by a
-// serial loop per lane).  Segment s has weight offset s * U, U = 64 * L = 2^log_u.
-//   window_sum = sum_s wacc_s + U * sum_s s * run_s
-template <class C>
-__global__ void __launch_bounds__(64)
-msm_reduce2_kernel(const Proj<C>* __restrict__ seg_run, const Proj<C>* __restrict__ seg_wacc,
-                   uint32_t segs_per_window, int log_u, Proj<C>* __restrict__ window_sums) {
-    extern __shared__ uint32_t lds_raw[];
-    Proj<C>* sh = reinterpret_cast<Proj<C>*>(lds_raw);
-    const int lane = threadIdx.x;
-    const uint32_t w = blockIdx.x;
-    const uint32_t per_lane = (segs_per_window + 63) / 64;  // consecutive segments per lane
-    Proj<C> run = proj_zero<C>(), wacc_w = proj_zero<C>(), plain = proj_zero<C>();
-    for (int i = (int)per_lane - 1; i >= 0; i--) {
-        const uint32_t s = lane * per_lane + i;
-        if (s < segs_per_window) {
-            run = proj_add_call<C>(run, ld_proj<C>(seg_run + (size_t)w * segs_per_window + s));
-            plain = proj_add_call<C>(plain, ld_proj<C>(seg_wacc + (size_t)w * segs_per_window + s));
-        }
-        if (i > 0) wacc_w = proj_add_call<C>(wacc_w, run);
-    }
-    // lane-local: weighted (in units of U) = wacc_w ; lane offset = lane * per_lane units
-    // total units-weighted sum = sum_l wacc_w_l + per_lane * sum_{l>=1} S_l
-    Proj<C> orun, ow;
-    // per_lane need not be a power of two: multiply S_l by per_lane with a small double-and-add
-    {
-        Proj<C> S = run;
-        for (int off = 1; off < 64; off <<= 1) {
-            st_proj<C>(sh + lane, S);
-            __syncthreads();
-            if (lane + off < 64) S = proj_add_call<C>(S, ld_proj<C>(sh + lane + off));
-            __syncthreads();
-        }
-        Proj<C> V = wacc_w;
-        if (lane >= 1) {
-            Proj<C> T = proj_zero<C>();
-            for (int b = 31; b >= 0; b--) {
-                T = proj_dbl_call<C>(T);
-                if ((per_lane >> b) & 1) T = proj_add_call<C>(T, S);
+    const uint32_t which = blockIdx.x / blocks_per_input, blk = blockIdx.x % blocks_per_input;
+    const WaveReduceIn<C> in = which == 0 ? in0 : (which == 1 ? in1 : in2);
+    const uint32_t w = blk / segs_per_window, seg = blk % segs_per_window;
+    const uint32_t item0 = seg * 64u * (uint32_t)L;
+    const int NS1 = in.mode == 1 ? L : 2 * L - 1;
+    const int NST = in.mode == 1 ? L + 6 : NS1 + 18;
+    Proj<C> run = proj_zero<C>(), wacc = proj_zero<C>(), tmp = proj_zero<C>();
+    int step = 0, det = 0, salt_id = 0;
+    bool mydet = false, mid_done = false;
+    Proj<C>* o = out + ((size_t)which * blocks_per_input + blk) * 3;
+    while (step < NST) {
+        int kind, off = 0, i = 0;
+        if (step < NS1) {
+            if (in.mode == 1) { kind = 0; i = L - 1 - step; }
+            else { kind = (step & 1) ? 1 : 0; i = L - 1 - (step >> 1); }
+        } else if (in.mode == 1) { kind = 4; off = 32 >> (step - NS1); }
+        else if (step < NS1 + 6) { kind = 2; off = 32 >> (step - NS1); }
+        else if (step < NS1 + 12) { kind = 3; off = 1 << (step - NS1 - 6); }
+        else {
+            kind = 4; off = 32 >> (step - NS1 - 12);
+            if (!mid_done) {   // between scan and the last tree: publish runW = S_0, drop lane 0 from the tree
+                if (lane == 0) { st_proj<C>(o, run); run = proj_zero<C>(); }
+                mid_done = true;
             }
-            V = proj_add_call<C>(V, T);
         }
-        ow = wave_tree_sum<C>(V, sh, lane);
+        const bool exch = kind >= 2;
+        if (exch && det == 0) st_proj<C>(sh + lane, kind == 2 ? wacc : run);
+        if (exch) __syncthreads();
+        bool active;
+        Proj<C> q = proj_zero<C>();
+        if (kind == 0) {
+            const uint32_t k = item0 + (uint32_t)lane + 64u * (uint32_t)i;
+            active = k < in.count;
+            if (active) q = ld_proj<C>(in.base + ((size_t)w * in.count + k) * in.stride + in.offset);
+        } else if (kind == 1) {
+            active = true;
+            q = run;
+        } else {
+            const int partner = lane + off;
+            active = kind == 3 ? partner < 64 : lane < off;
+            if (active) q = ld_proj<C>(sh + partner);
+        }
+        if (exch) __syncthreads();
+        const bool to_wacc = kind == 1 || kind == 2;
+        Proj<C> p = to_wacc ? wacc : run;
+        if (det > 0) {
+            active = mydet;
+            if (det >= 2) p = tmp;
+            if (det != 2) {
+                Aff<C> s = ld_aff<C>(salts + salt_id);
+                q.x = s.x; q.y = det == 3 ? F::neg(s.y) : s.y; q.z = F::one();
+            }
+        }
+        bool same;
+        Proj<C> r = proj_add_sel<C>(p, q, same);
+        same = same && active;
+        if (det == 0) {
+            const bool any_same = __any(same) != 0;
+            if (active && !same) { if (to_wacc) wacc = r; else run = r; }
+            if (any_same) {
+                mydet = same;
+                if (same) {   // salt with x != p.x / p.z  (rare path: out-of-line product)
+                    Aff<C> s0 = ld_aff<C>(salts);
+                    salt_id = C::FC::eq(C::FC::mul(s0.x, p.z), p.x) ? 1 : 0;
+                }
+                det = 1;
+            } else {
+                step++;
+            }
+        } else {
+            if (mydet) {
+                if (det < 3) tmp = r;
+                else if (to_wacc) wacc = r; else run = r;
+            }
+            if (det == 3) { det = 0; mydet = false; step++; } else det++;
+        }
     }
-    Proj<C> pl = wave_tree_sum<C>(plain, sh, lane);
     if (lane == 0) {
-        for (int d = 0; d < log_u; d++) ow = proj_dbl_call<C>(ow);
-        st_proj<C>(window_sums + w, proj_add_call<C>(pl, ow));
+        if (in.mode == 1) {
+            st_proj<C>(o, run);
+        } else {
+            st_proj<C>(o + 1, wacc);
+            st_proj<C>(o + 2, run);
+        }
     }
 }
 

@@ -3,6 +3,7 @@
 // Test infrastructure only; not part of the product library.
 #include <string.h>
 #include "../../ginger-lib_amd/csrc/ec29.h"
+#include "../../ginger-lib_amd/csrc/host_math.h"
 
 using namespace gh;
 
@@ -56,7 +57,36 @@ template <class C> static void ec_op(int op, const uint32_t* p, const uint32_t* 
     F::to_abi(out + 2 * W, r.z);
 }
 
+template <class P> static void h64_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out) {
+    typedef HF1<P> F;
+    H64 x, y, r;
+    memcpy(x.l, a, 96); memcpy(y.l, b, 96);
+    switch (op) {
+        case 0: r = F::mul(x, y); break;
+        case 2: r = F::add(x, y); break;
+        case 3: r = F::sub(x, y); break;
+        case 4: r = F::neg(x); break;
+        case 5: r = F::dbl(x); break;
+        case 8: r = F::mul_small(x, 11); break;
+        default: r = F::zero();
+    }
+    memcpy(out, r.l, 96);
+}
+// G1 doubling / addition on the fast host field (ABI Montgomery limbs in and out)
+template <class HC> static void h64_ec(int op, const uint64_t* p, const uint64_t* q, uint64_t* out) {
+    Proj<HC> a, b, r;
+    memcpy(&a, p, sizeof a); memcpy(&b, q, sizeof b);
+    r = op == 0 ? proj_add<HC>(a, b) : proj_dbl<HC>(a);
+    memcpy(out, &r, sizeof r);
+}
+
 extern "C" {
+void t_h64_op(int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out) {
+    if (field == 4) h64_op<P4>(op, a, b, out); else h64_op<P6>(op, a, b, out);
+}
+void t_h64_ec(int field, int op, const uint64_t* p, const uint64_t* q, uint64_t* out) {
+    if (field == 4) h64_ec<HostMnt4G1>(op, p, q, out); else h64_ec<HostMnt6G1>(op, p, q, out);
+}
 void t_fp_op(int field, int op, const uint32_t* a, const uint32_t* b, uint32_t* out) {
     if (field == 4) fp_op<P4>(op, a, b, out); else fp_op<P6>(op, a, b, out);
 }

@@ -102,3 +102,47 @@ def test_curve_ops(shim, cid, name):
     assert result(out) == C.add(P, P)
     shim.t_ec_op(cid, 2, proj(None), proj(None), out)
     assert result(out) is None
+
+
+@pytest.mark.parametrize("fid,F,curve", [(4, pyref.P4, "mnt4753_g1"), (6, pyref.P6, "mnt6753_g1")])
+def test_host_fold_field(shim, fid, F, curve):
+    """the 12 x u64 host field used by the window fold (host_math.h HF1) and G1 add/double on it"""
+    import numpy as np
+    p = F.p
+    rng = pyref.Rng(55 + fid)
+    U64 = ctypes.c_uint64
+
+    def w64(x, n=12):
+        return (U64 * n)(*[(x >> (64 * i)) & (2**64 - 1) for i in range(n)])
+
+    def i64(w):
+        return sum(int(v) << (64 * i) for i, v in enumerate(w))
+    for it in range(200):
+        a, b = rng.field_elem(p), rng.field_elem(p)
+        if it == 0:
+            a = 0
+        if it == 1:
+            a = b = p - 1
+        out = (U64 * 12)()
+        for op, e in ((0, a * b * F.Rinv % p), (2, (a + b) % p), (3, (a - b) % p), (4, -a % p), (5, 2 * a % p), (8, 11 * a % p)):
+            shim.t_h64_op(fid, op, w64(a), w64(b), out)
+            assert i64(out) == e, (op, it)
+    C = pyref.CURVES[curve]
+    P, Q = C.mul(777, C.G), C.mul(31337, C.G)
+
+    def proj(Pt, z):
+        if Pt is None:
+            return w64(0 | (F.to_mont(1) << 768), 36)
+        X, Y = (Pt[0][0] * z) % p, (Pt[1][0] * z) % p
+        return w64(F.to_mont(X) | (F.to_mont(Y) << 768) | (F.to_mont(z) << 1536), 36)
+
+    def aff(out):
+        v = i64(out)
+        X, Y, Z = (F.from_mont((v >> (768 * k)) & (2**768 - 1)) for k in range(3))
+        return C.proj_to_affine((X,), (Y,), (Z,))
+    out = (U64 * 36)()
+    for A, B in ((P, Q), (P, P), (P, C.neg(P)), (None, Q), (P, None)):
+        shim.t_h64_ec(fid, 0, proj(A, 5), proj(B, 9), out)
+        assert aff(out) == C.add(A, B)
+    shim.t_h64_ec(fid, 1, proj(P, 3), proj(P, 3), out)
+    assert aff(out) == C.add(P, P)
