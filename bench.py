@@ -44,19 +44,25 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     device = None
+    backend = os.environ.get("GH_DIST_BACKEND", "nccl")   # "gloo" only to rehearse the N > 1 path on a one-GPU box
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        device = torch.device("cuda", local_rank)
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            device = torch.device("cuda", local_rank)
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     import pyref
     from __graft_entry__ import _load_pkg
     gl = _load_pkg()
     import importlib
     distmod = importlib.import_module("ginger_lib_amd.dist")
-    gl.init(local_rank)          # raises if the HIP library or a gfx950 device is missing: no fallback
+    # raises if the HIP library or a gfx950 device is missing: no fallback.  (gloo rehearsal on a one-GPU
+    # box: let the library map LOCAL_RANK modulo the device count.)
+    gl.init(local_rank if (world == 1 or backend == "nccl") else None)
     if args.window:
         gl.msm_set_window(args.window)
 
@@ -90,8 +96,9 @@ def main():
         load = gl.load_library()
         load.gh_dev_sync()
         if world > 1:
-            import torch
-            torch.cuda.synchronize()
+            if device is not None:
+                import torch
+                torch.cuda.synchronize()
             dist.barrier()
 
     for _ in range(args.warmup):
@@ -110,7 +117,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if world > 1:
         import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if device is not None else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     value = world * n * args.steps / elapsed

@@ -32,7 +32,7 @@ ABI_SYMBOLS = [
     "gh_msm", "gh_bases_upload", "gh_bases_free", "gh_bases_len", "gh_msm_resident", "gh_msm_resident_dev",
     "gh_msm_set_window", "gh_msm_get_window", "gh_msm_last_timing",
     "gh_domain_supported", "gh_fft", "gh_fft_dev", "gh_vec_mul_dev", "gh_vec_sub_dev", "gh_vec_scale_dev",
-    "gh_vec_mul", "gh_vec_scale", "gh_fft_last_kernel_ms",
+    "gh_vec_mul", "gh_vec_scale", "gh_fft_last_kernel_ms", "gh_witness_map", "gh_witness_map_dev",
     "gh_dev_alloc", "gh_dev_free", "gh_dev_upload", "gh_dev_download", "gh_dev_sync",
     "gh_proj_add", "gh_proj_to_affine",
 ]
@@ -86,6 +86,8 @@ def load_library():
     lib.gh_vec_mul.argtypes = [ci, vp, vp, sz]
     lib.gh_vec_scale.argtypes = [ci, vp, vp, sz]
     lib.gh_fft_last_kernel_ms.argtypes = [ctypes.POINTER(ctypes.c_float)]
+    lib.gh_witness_map.argtypes = [ci, vp, vp, vp, u32, vp, vp, vp, vp]
+    lib.gh_witness_map_dev.argtypes = [ci, vp, vp, vp, u32, vp, vp, vp, vp]
     lib.gh_dev_alloc.argtypes = [ctypes.POINTER(vp), sz]
     lib.gh_dev_free.argtypes = [vp]
     lib.gh_dev_upload.argtypes = [vp, vp, sz]
@@ -285,6 +287,19 @@ class EvaluationDomain:
         assert a.size == b.size
         _check(load_library().gh_vec_mul(FIELDS[self.field], _ptr(a), _ptr(b), a.size // 12))
         return a
+
+
+def witness_map(field, a, b, c, d1, d2, d3):
+    """Transform part of R1CStoQAP::witness_map (r1cs_to_qap.rs:121-166): a, b, c are the 2^k
+    evaluations of the A, B, C rows (Montgomery, 12 u64 each); returns the 2^k + 1 coefficients of h."""
+    a, b, c = _u64(a, 12), _u64(b, 12), _u64(c, 12)
+    n = a.size // 12
+    assert n and (n & (n - 1)) == 0 and b.size == a.size and c.size == a.size
+    log_n = n.bit_length() - 1
+    d1, d2, d3 = _u64(d1, 12), _u64(d2, 12), _u64(d3, 12)
+    h = np.empty((n + 1) * 12, dtype=np.uint64)
+    _check(load_library().gh_witness_map(FIELDS[field], _ptr(a), _ptr(b), _ptr(c), log_n, _ptr(d1), _ptr(d2), _ptr(d3), _ptr(h)))
+    return h
 
 
 def vec_scale(field, a, scalar12):

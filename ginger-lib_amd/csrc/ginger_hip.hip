@@ -266,6 +266,34 @@ int gh_fft(gh_field_t field, const uint64_t* in, size_t n_in, uint64_t* out, uin
     return GH_OK;
 }
 
+int gh_witness_map_dev(gh_field_t field, void* d_a, void* d_b, void* d_c, uint32_t log_n, const uint64_t* d1,
+                       const uint64_t* d2, const uint64_t* d3, void* d_h) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!d_a || !d_b || !d_c || !d_h || !d1 || !d2 || !d3) { g_err = "null argument"; return GH_E_BAD_ARG; }
+    int rc = ensure_init();
+    if (rc) return rc;
+    return witness_map(field, d_a, d_b, d_c, log_n, d1, d2, d3, d_h);
+}
+
+int gh_witness_map(gh_field_t field, const uint64_t* a, const uint64_t* b, const uint64_t* c, uint32_t log_n,
+                   const uint64_t* d1, const uint64_t* d2, const uint64_t* d3, uint64_t* h) {
+    if (!a || !b || !c || !h || !d1 || !d2 || !d3) { g_err = "null argument"; return GH_E_BAD_ARG; }
+    if (log_n >= 31) { g_err = "domain too large"; return GH_E_UNSUPPORTED; }
+    const size_t N = (size_t)1 << log_n, bytes = N * 96;
+    void *da = nullptr, *db = nullptr, *dc = nullptr, *dh = nullptr;
+    int rc = gh_dev_alloc(&da, bytes);
+    if (!rc) rc = gh_dev_alloc(&db, bytes);
+    if (!rc) rc = gh_dev_alloc(&dc, bytes);
+    if (!rc) rc = gh_dev_alloc(&dh, bytes + 96);
+    if (!rc) rc = gh_dev_upload(da, a, bytes);
+    if (!rc) rc = gh_dev_upload(db, b, bytes);
+    if (!rc) rc = gh_dev_upload(dc, c, bytes);
+    if (!rc) rc = gh_witness_map_dev(field, da, db, dc, log_n, d1, d2, d3, dh);
+    if (!rc) rc = gh_dev_download(h, dh, bytes + 96);
+    gh_dev_free(da); gh_dev_free(db); gh_dev_free(dc); gh_dev_free(dh);
+    return rc;
+}
+
 int gh_fft_last_kernel_ms(float* ms) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (ms) *ms = g.last_fft_ms;

@@ -106,7 +106,7 @@ template <class P> int fft_run(int fidx, void* d_data, uint32_t log_n, uint32_t 
         A.k = ks[s];
         A.log_ns = log_ns;
         int log_c = (int)log_n - ks[s];
-        if (log_c > 10 - ks[s]) log_c = 10 - ks[s];
+        if (log_c > NTT_LOG_TILE - ks[s]) log_c = NTT_LOG_TILE - ks[s];
         A.log_c = log_c;
         A.inverse = inverse ? 1 : 0;
         const int E = 1 << (ks[s] + log_c);
@@ -138,6 +138,52 @@ template <class P> int vec_op(int op, void* d_a, const void* d_b, const uint64_t
     return GH_OK;
 }
 
+
+// R1CStoQAP::witness_map, transform part (proof-systems/src/groth16/r1cs_to_qap.rs:121-166)
+template <class P> int witness_map_t(int fidx, void* d_a, void* d_b, void* d_c, uint32_t log_n, const uint64_t* d1,
+                                     const uint64_t* d2, const uint64_t* d3, void* d_h) {
+    const size_t N = (size_t)1 << log_n;
+    int rc;
+    // a, b -> coefficients -> evaluations on the coset (:121-122, :134-135)
+    if ((rc = fft_run<P>(fidx, d_a, log_n, GH_FFT_INVERSE))) return rc;
+    if ((rc = fft_run<P>(fidx, d_b, log_n, GH_FFT_INVERSE))) return rc;
+    if ((rc = fft_run<P>(fidx, d_a, log_n, GH_FFT_COSET))) return rc;
+    if ((rc = fft_run<P>(fidx, d_b, log_n, GH_FFT_COSET))) return rc;
+    if ((rc = vec_op<P>(0, d_a, d_b, nullptr, N))) return rc;                        // ab = a .* b (:137)
+    if ((rc = fft_run<P>(fidx, d_c, log_n, GH_FFT_INVERSE))) return rc;              // :153
+    if ((rc = fft_run<P>(fidx, d_c, log_n, GH_FFT_COSET))) return rc;                // :154
+    if ((rc = vec_op<P>(1, d_a, d_c, nullptr, N))) return rc;                        // ab -= c (:156-158)
+    // divide_by_vanishing_poly_on_coset: multiply by (g^N - 1)^-1  (domain.rs:245-256, :229-231)
+    Fp gen = fp_from_abi<P>(reinterpret_cast<const uint32_t*>(FieldConsts<P>::gen_m()));
+    Fp gn = gen;
+    for (uint32_t i = 0; i < log_n; i++) gn = fp_sqr<P>(gn);
+    Fp vinv = host_fp_inv<P>(fp_sub<P>(gn, fp_one<P>()));
+    uint64_t vinv_abi[12];
+    fp_to_abi<P>(reinterpret_cast<uint32_t*>(vinv_abi), vinv);
+    if ((rc = vec_op<P>(2, d_a, nullptr, vinv_abi, N))) return rc;
+    if ((rc = fft_run<P>(fidx, d_a, log_n, GH_FFT_INVERSE | GH_FFT_COSET))) return rc;   // :161
+    // h (:124-132, :163-166)
+    Fp f1 = fp_from_abi<P>(reinterpret_cast<const uint32_t*>(d1)), f2 = fp_from_abi<P>(reinterpret_cast<const uint32_t*>(d2));
+    Fp f3 = fp_from_abi<P>(reinterpret_cast<const uint32_t*>(d3));
+    Fp d1d2 = fp_mul<P>(f1, f2);
+    Fp h0 = fp_neg<P>(fp_add<P>(f3, d1d2));
+    uint32_t w0[24], w1[24];
+    fp_to_abi<P>(w0, h0);
+    fp_to_abi<P>(w1, d1d2);
+    hipLaunchKernelGGL((witness_finish_kernel<P>), dim3((unsigned)((N + 1 + 255) / 256)), dim3(256), 0, g.stream,
+                       (const uint32_t*)d_a, (uint32_t*)d_h, N, fp_unpack(w0), fp_unpack(w1));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(g.stream));
+    return GH_OK;
+}
+
+int witness_map(gh_field_t field, void* d_a, void* d_b, void* d_c, uint32_t log_n, const uint64_t* d1,
+                const uint64_t* d2, const uint64_t* d3, void* d_h) {
+    if (field == GH_MNT4753_FR) return witness_map_t<P6>(0, d_a, d_b, d_c, log_n, d1, d2, d3, d_h);
+    if (field == GH_MNT6753_FR) return witness_map_t<P4>(1, d_a, d_b, d_c, log_n, d1, d2, d3, d_h);
+    g_err = "unknown field id";
+    return GH_E_BAD_ARG;
+}
 
 int fft_run(gh_field_t field, void* d_data, uint32_t log_n, uint32_t flags) {
     if (field == GH_MNT4753_FR) return fft_run<P6>(0, d_data, log_n, flags);

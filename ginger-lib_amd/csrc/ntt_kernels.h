@@ -9,7 +9,7 @@
 // elements, so only the values matter; the schedule here is chosen for the GPU:
 //
 //   N = 2^n is factored into P = ceil(n/8) passes of radix R_s = 2^k_s (k_s <= 8).  Pass s is a
-//   Stockham (self-sorting, out-of-place) step: block b owns C consecutive column indices
+//   Stockham (self-sorting, out-of-place) step: block b owns C = 512 / R consecutive column indices
 //   j in [bC, bC+C) and all R rows t; it reads x[j + t N/R] (rows are C*96-byte contiguous runs),
 //   multiplies by the inter-pass twiddle w_(Ns R)^((j mod Ns) t) (pass 0: by the coset factor g^i
 //   instead, if any), runs the R-point DFT as k radix-2 DIF stages through LDS (one butterfly per
@@ -28,7 +28,12 @@
 
 namespace gh {
 
-constexpr int NTT_MAX_TILE = 1024;  // elements per block tile (26 * 4 B * 1024 = 104 KiB of LDS)
+// Elements per block tile.  The kernel needs ~256 VGPRs, i.e. 2 waves per SIMD = 512 threads per
+// CU.  One 512-thread block per CU (1024-element tile) leaves nothing to run while that block
+// sits at a barrier or in its load / store phase; two 256-thread blocks (512-element tiles,
+// 52 KiB of LDS each) overlap each other.
+constexpr int NTT_LOG_TILE = 9;
+constexpr int NTT_MAX_TILE = 1 << NTT_LOG_TILE;
 constexpr int NTT_MAX_LOGR = 8;
 
 __device__ __forceinline__ Fp ld_fp(const Fp* p) {
@@ -73,7 +78,7 @@ struct NttPassArgs {
 __device__ __forceinline__ uint32_t bitrev_k(uint32_t t, int k) { return __brev(t) >> (32 - k); }
 
 template <class P>
-__global__ void __launch_bounds__(512) ntt_pass_kernel(NttPassArgs A) {
+__global__ void __launch_bounds__(NTT_MAX_TILE / 2, 2) ntt_pass_kernel(NttPassArgs A) {
     extern __shared__ uint32_t lds[];  // [NL][E]
     const int k = A.k, log_c = A.log_c;
     const int R = 1 << k, C = 1 << log_c, E = R << log_c;
@@ -188,6 +193,21 @@ __global__ void __launch_bounds__(256) vec_op_kernel(uint32_t* a, const uint32_t
         x = fp_mul<P>(x, scalar_int);  // scalar in internal form: raw * s
     }
     st_abi_raw(a + i * 24, x);
+}
+
+// last step of witness_map (r1cs_to_qap.rs:124-132, :163-166): h[0 .. N] from ab[0 .. N)
+//   h[0] = ab[0] + h0_add;  h[i] = ab[i] (0 < i < N-1);  h[N-1] = 0;  h[N] = h_last
+// ab / h in ABI layout; h0_add, h_last are ABI-Montgomery values unpacked to raw limbs (plain
+// modular add works on raw residues).
+template <class P>
+__global__ void __launch_bounds__(256) witness_finish_kernel(const uint32_t* ab, uint32_t* h, size_t N, Fp h0_add, Fp h_last) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > N) return;
+    Fp v;
+    if (i == N) v = h_last;
+    else if (i == N - 1) v = fp_zero();
+    else { v = ld_abi_raw(ab + i * 24); if (i == 0) v = fp_add<P>(v, h0_add); }
+    st_abi_raw(h + i * 24, v);
 }
 
 // ABI Montgomery -> internal Montgomery for a vector of n elements (table seeds etc.)

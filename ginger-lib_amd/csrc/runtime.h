@@ -81,5 +81,7 @@ const MsmOps* msm_ops_mnt6753_g2();
 // ---- transforms (ntt.hip)
 int fft_run(gh_field_t field, void* d_data, uint32_t log_n, uint32_t flags);
 int vec_op(gh_field_t field, int op, void* d_a, const void* d_b, const uint64_t* scalar12, size_t n);
+int witness_map(gh_field_t field, void* d_a, void* d_b, void* d_c, uint32_t log_n, const uint64_t* d1,
+                const uint64_t* d2, const uint64_t* d3, void* d_h);
 
 }  // namespace gh_rt

@@ -12,6 +12,7 @@
  *   algebra/src/fft/domain.rs:155-179        coset_fft / coset_ifft (_in_place)   -> gh_fft_* + GH_FFT_COSET
  *   algebra/src/fft/domain.rs:245-256        divide_by_vanishing_poly_on_coset_in_place -> gh_vec_scale_*
  *   algebra/src/fft/domain.rs:289-302        mul_polynomials_in_evaluation_domain -> gh_vec_mul_*
+ *   proof-systems/src/groth16/r1cs_to_qap.rs:121-166  witness_map (transform part) -> gh_witness_map(_dev)
  *
  * Data formats (exactly the reference's in-memory values, marshalled field by field because the
  * Rust structs are not repr(C) -- SURVEY.md section 8b):
@@ -141,6 +142,22 @@ int gh_vec_scale_dev(gh_field_t field, void* d_a, const uint64_t* scalar12, size
 /* Host-buffer forms of the same (copy in, compute, copy out). */
 int gh_vec_mul(gh_field_t field, uint64_t* a, const uint64_t* b, size_t n);
 int gh_vec_scale(gh_field_t field, uint64_t* a, const uint64_t* scalar12, size_t n);
+
+/* QAP witness map, device resident: the transform part of R1CStoQAP::witness_map
+ * (proof-systems/src/groth16/r1cs_to_qap.rs:121-166).  d_a, d_b, d_c hold the 2^log_n evaluations
+ * of the A, B, C rows at the assignment (:105-119, :141-151; computed by the caller -- circuit
+ * synthesis is CPU scalar code and out of scope); they are overwritten.  d_h receives the
+ * 2^log_n + 1 coefficients of h:
+ *   a = coset_fft(ifft(a)); b = coset_fft(ifft(b)); ab = a .* b; c = coset_fft(ifft(c));
+ *   ab = (ab - c) * (g^N - 1)^-1; ab = coset_ifft(ab);
+ *   h[0] = ab[0] - d3 - d1 d2;  h[i] = ab[i] (0 < i < N-1);  h[N-1] = 0;  h[N] = d1 d2
+ * (h starts as zeros and `*h_i *= ...` in :124-129 leaves it zero -- reproduced as is).
+ * d1, d2, d3: 12-u64 Montgomery field elements on the host.                                  */
+int gh_witness_map_dev(gh_field_t field, void* d_a, void* d_b, void* d_c, uint32_t log_n,
+                       const uint64_t* d1, const uint64_t* d2, const uint64_t* d3, void* d_h);
+/* Host-buffer form: a, b, c of 2^log_n elements each (not modified), h of 2^log_n + 1 elements. */
+int gh_witness_map(gh_field_t field, const uint64_t* a, const uint64_t* b, const uint64_t* c, uint32_t log_n,
+                   const uint64_t* d1, const uint64_t* d2, const uint64_t* d3, uint64_t* h);
 
 /* Duration of the kernels of the last gh_fft / gh_fft_dev call (HIP events), milliseconds. */
 int gh_fft_last_kernel_ms(float* ms);

@@ -593,4 +593,35 @@ template <class P> void domain_transform(const Domain<P>& d, Fp<P>* a, size_t n_
     }
 }
 
+// ---- proof-systems/src/groth16/r1cs_to_qap.rs:121-166  witness_map, from the evaluated rows on
+// (a, b, c: domain-size vectors, already holding the constraint evaluations and the input rows).
+template <class P>
+void witness_map(std::vector<Fp<P>>& a, std::vector<Fp<P>>& b, std::vector<Fp<P>>& c, uint32_t log_n,
+                 const Fp<P>& d1, const Fp<P>& d2, const Fp<P>& d3, std::vector<Fp<P>>& h, int threads) {
+    typedef Fp<P> F;
+    Domain<P> d;
+    Domain<P>::create((size_t)1 << log_n, d);
+    const size_t n = d.size;
+    domain_transform<P>(d, a.data(), n, true, false, threads);                    // ifft_in_place(a)  :121
+    domain_transform<P>(d, b.data(), n, true, false, threads);                    // ifft_in_place(b)  :122
+    h.assign(n, F::zero());                                                       // :124
+    for (size_t i = 0; i < n; i++) { F t = d2.mul(a[i]).add(d1.mul(b[i])); h[i].mul_assign(t); }   // :125-128 (zero *= ...)
+    h[0].sub_assign(d3);                                                          // :129
+    F d1d2 = d1.mul(d2);                                                          // :130
+    h[0].sub_assign(d1d2);                                                        // :131
+    h.push_back(d1d2);                                                            // :132
+    domain_transform<P>(d, a.data(), n, false, true, threads);                    // coset_fft(a) :134
+    domain_transform<P>(d, b.data(), n, false, true, threads);                    // coset_fft(b) :135
+    std::vector<F> ab(a);
+    for (size_t i = 0; i < n; i++) ab[i].mul_assign(b[i]);                        // :137
+    domain_transform<P>(d, c.data(), n, true, false, threads);                    // :153
+    domain_transform<P>(d, c.data(), n, false, true, threads);                    // :154
+    for (size_t i = 0; i < n; i++) ab[i].sub_assign(c[i]);                        // :156-158
+    uint64_t e = n;                                                               // divide_by_vanishing_poly_on_coset (domain.rs:245-256)
+    F vi; F::multiplicative_generator().pow(&e, 1).sub(F::one()).inverse(vi);
+    for (size_t i = 0; i < n; i++) ab[i].mul_assign(vi);                          // :160
+    domain_transform<P>(d, ab.data(), n, true, true, threads);                    // coset_ifft :161
+    for (size_t i = 0; i + 1 < n; i++) h[i].add_assign(ab[i]);                    // :163-166
+}
+
 }  // namespace oracle

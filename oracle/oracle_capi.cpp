@@ -192,4 +192,23 @@ int oracle_vanishing_inv_on_coset(int field, uint32_t log_n, uint64_t* out) {
     else { Fp<P4> g = Fp<P4>::multiplicative_generator().pow(&e, 1).sub(Fp<P4>::one()), r; g.inverse(r); memcpy(out, r.v.l, 96); }
     return 0;
 }
+// witness_map (r1cs_to_qap.rs:121-166) from evaluated rows; h_out receives 2^log_n + 1 elements
+int oracle_witness_map(int field, const uint64_t* a, const uint64_t* b, const uint64_t* c, uint32_t log_n,
+                       const uint64_t* d1, const uint64_t* d2, const uint64_t* d3, uint64_t* h_out, int threads) {
+    const size_t n = (size_t)1 << log_n;
+    if (field == 0) {
+        std::vector<Fp<P6>> va(n), vb(n), vc(n), h;
+        memcpy(va.data(), a, n * 96); memcpy(vb.data(), b, n * 96); memcpy(vc.data(), c, n * 96);
+        Fp<P6> f1, f2, f3; memcpy(f1.v.l, d1, 96); memcpy(f2.v.l, d2, 96); memcpy(f3.v.l, d3, 96);
+        witness_map<P6>(va, vb, vc, log_n, f1, f2, f3, h, threads);
+        memcpy(h_out, h.data(), (n + 1) * 96);
+    } else {
+        std::vector<Fp<P4>> va(n), vb(n), vc(n), h;
+        memcpy(va.data(), a, n * 96); memcpy(vb.data(), b, n * 96); memcpy(vc.data(), c, n * 96);
+        Fp<P4> f1, f2, f3; memcpy(f1.v.l, d1, 96); memcpy(f2.v.l, d2, 96); memcpy(f3.v.l, d3, 96);
+        witness_map<P4>(va, vb, vc, log_n, f1, f2, f3, h, threads);
+        memcpy(h_out, h.data(), (n + 1) * 96);
+    }
+    return 0;
+}
 }

@@ -33,6 +33,7 @@ def oracle():
         lib.oracle_domain.argtypes = [ci, sz, vp, ctypes.POINTER(u32)]
         lib.oracle_vec_mul.argtypes = [ci, vp, vp, sz]
         lib.oracle_vanishing_inv_on_coset.argtypes = [ci, u32, vp]
+        lib.oracle_witness_map.argtypes = [ci, vp, vp, vp, u32, vp, vp, vp, vp, ci]
         _oracle = lib
     return _oracle
 
@@ -164,3 +165,17 @@ def oracle_fft(field, a, log_n, flags, threads=8):
     rc = oracle().oracle_fft(FIELD_ID[field], ptr(buf), n_in, log_n, flags, threads)
     assert rc == 0
     return buf
+
+
+def oracle_witness_map(field, a, b, c, d1, d2, d3, threads=8):
+    """restated R1CStoQAP::witness_map (r1cs_to_qap.rs:121-166) from evaluated rows -> h (N + 1 elements)"""
+    a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 12)
+    n = len(a)
+    log_n = n.bit_length() - 1
+    b = np.ascontiguousarray(b, dtype=np.uint64)
+    c = np.ascontiguousarray(c, dtype=np.uint64)
+    h = np.zeros((n + 1, 12), dtype=np.uint64)
+    d1, d2, d3 = (np.ascontiguousarray(x, dtype=np.uint64) for x in (d1, d2, d3))
+    rc = oracle().oracle_witness_map(FIELD_ID[field], ptr(a), ptr(b), ptr(c), log_n, ptr(d1), ptr(d2), ptr(d3), ptr(h), threads)
+    assert rc == 0
+    return h

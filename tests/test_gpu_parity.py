@@ -99,6 +99,22 @@ def test_vec_ops(gpu):
     assert (got == exp).all()
 
 
+@pytest.mark.parametrize("field,log_n", [("mnt4753_fr", 1), ("mnt4753_fr", 10), ("mnt4753_fr", 15), ("mnt6753_fr", 9)])
+def test_witness_map_vs_oracle(gpu, field, log_n):
+    """R1CStoQAP::witness_map transform pipeline (r1cs_to_qap.rs:121-166), arbitrary rows and d1 d2 d3"""
+    F = S.FIELD_OF[field]
+    n = 1 << log_n
+    a, b, c = (S.random_scalars_np(n, seed=s0 + log_n, below=F.p) for s0 in (100, 200, 300))
+    for ds in (([0] * 3), None):
+        if ds is None:
+            d = S.random_scalars_np(3, seed=9, below=F.p)
+        else:
+            d = np.zeros((3, 12), dtype=np.uint64)
+        got = gpu.witness_map(field, a, b, c, d[0], d[1], d[2]).reshape(n + 1, 12)
+        exp = S.oracle_witness_map(field, a, b, c, d[0], d[1], d[2], 16)
+        assert (got == exp).all()
+
+
 # ------------------------------------------------------------------------------ MSM
 def load_msm_case(name):
     case = MSM_G[name]

@@ -103,3 +103,34 @@ def test_oracle_domain_limits():
     assert o.oracle_domain(1, 1 << 14, S.ptr(out), ctypes.byref(lg)) == 1
     assert o.oracle_domain(1, (1 << 14) + 1, S.ptr(out), ctypes.byref(lg)) == 0      # MNT6 Fr: two-adicity 15
     assert o.oracle_domain(0, 0, S.ptr(out), ctypes.byref(lg)) == 1 and lg.value == 0  # new(0) -> size 1
+
+
+def test_oracle_witness_map_first_principles():
+    """witness_map (r1cs_to_qap.rs:121-166): for rows satisfying a_i b_i = c_i on the domain, h must be
+    the exact quotient (A B - C) / (X^N - 1); with d1 d2 d3 the reference's h[0] / h[N] corrections."""
+    F = pyref.P6
+    p = F.p
+    log_n, n = 3, 8
+    rng = pyref.Rng(4)
+    a = [rng.field_elem(p) for _ in range(n)]
+    b = [rng.field_elem(p) for _ in range(n)]
+    c = [(x * y) % p for x, y in zip(a, b)]
+    pa, pb, pc = (pyref.ntt_fast(F, v, log_n, inverse=True) for v in (a, b, c))
+    prod = [0] * (2 * n - 1)
+    for i, x in enumerate(pa):
+        for j, y in enumerate(pb):
+            prod[i + j] = (prod[i + j] + x * y) % p
+    for i, x in enumerate(pc):
+        prod[i] = (prod[i] - x) % p
+    q = [0] * (n - 1)
+    for i in range(2 * n - 2, n - 1, -1):
+        q[i - n] = prod[i]
+        prod[i - n] = (prod[i - n] + prod[i]) % p
+        prod[i] = 0
+    assert not any(prod)
+    A, B, C = S.fe_array(F, a), S.fe_array(F, b), S.fe_array(F, c)
+    z = S.fe_array(F, [0])
+    assert S.fe_list(F, S.oracle_witness_map("mnt4753_fr", A, B, C, z, z, z)) == q + [0, 0]
+    d1, d2, d3 = (rng.field_elem(p) for _ in range(3))
+    h = S.fe_list(F, S.oracle_witness_map("mnt4753_fr", A, B, C, S.fe_array(F, [d1]), S.fe_array(F, [d2]), S.fe_array(F, [d3])))
+    assert h == [(q[0] - d3 - d1 * d2) % p] + q[1:] + [0, (d1 * d2) % p]
