@@ -66,14 +66,20 @@ int device_scan(const uint32_t* in, uint32_t* out, size_t n, const char* tmpname
     return GH_OK;
 }
 
+// Window size.  Measured on MI355X (profiles/r01_window_sweep.txt): besides the usual trade of
+// accumulate work (n * ceil(754/c) additions) against bucket-reduction work (2^(c-1) buckets per
+// window), what matters is how full the TOP window is -- c = 13 (58 * 13 = 754), 18 (42 * 18 = 756),
+// 19 and 21 leave no sparsely populated top window whose few buckets become over-long.
 int auto_window(size_t n) {
     if (g.window_override > 0) return g.window_override;
     int lg = 0;
     while (((size_t)1 << (lg + 1)) <= n) lg++;
-    int c = lg - 4;
-    if (c < 4) c = 4;
-    if (c > 20) c = 20;
-    return c;
+    if (lg >= 23) return 19;
+    if (lg >= 21) return 18;
+    if (lg >= 19) return 16;
+    if (lg >= 15) return 13;
+    int c = lg - 3;
+    return c < 4 ? 4 : c;
 }
 
 static const MsmOps* ops_of(gh_curve_t curve) {

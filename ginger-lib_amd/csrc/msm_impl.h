@@ -47,6 +47,15 @@ template <> struct GenConst<Mnt6G2> { static void get(uint64_t* xy) {
     static const uint64_t y0[12] = GH_MNT6753_G2_GY0_M_64, y1[12] = GH_MNT6753_G2_GY1_M_64, y2[12] = GH_MNT6753_G2_GY2_M_64;
     memcpy(xy, x0, 96); memcpy(xy + 12, x1, 96); memcpy(xy + 24, x2, 96); memcpy(xy + 36, y0, 96); memcpy(xy + 48, y1, 96); memcpy(xy + 60, y2, 96); } };
 
+// scalar-field modulus of the curve (MNT4: r = p6, MNT6: r = p4) as 24 LE 32-bit words
+template <class C> MsmModulus scalar_modulus() {
+    static const uint32_t r4[24] = GH_P6_P_32, r6[24] = GH_P4_P_32;
+    const bool mnt4 = CurveId<C>::id == GH_MNT4753_G1 || CurveId<C>::id == GH_MNT4753_G2;
+    MsmModulus m;
+    memcpy(m.w, mnt4 ? r4 : r6, sizeof m.w);
+    return m;
+}
+
 template <class C> int make_salts(Aff<C>* out) {
     typedef typename C::F F;
     uint64_t xy[72];
@@ -92,27 +101,53 @@ int upload_bases(const uint64_t* bases, const uint8_t* infinity, size_t n, Bases
 }
 
 // Horner over windows, high to low (variable_base.rs:73-82).  Per window the device delivers
-// (PW, PS, PA, PB) with  R_w = PW 2^(u+6) + PS 2^u + PA 2^6 + PB;  the terms of
-// acc * 2^c + R_w are folded by descending exponent so that the powers of two cost no doubling
-// beyond the c per window that the Horner step needs anyway.  HC is the curve policy the fold
-// runs on: the fast 64-bit-limb host field for G1, the generic rr29 code otherwise.
+// (T, PW, PS, PA, PB) with  R_w = PW 2^(u+6) + PS 2^u + PA 2^6 + PB  and T = plain sum of the
+// window's buckets; the terms of acc * 2^c + R_w are folded by descending exponent so that the
+// powers of two cost no doubling beyond the c per window that the Horner step needs anyway.
+// top_unsigned: window W-1 is "region b" of window W-2 (slot offset 2^(c-1)):
+//   R_top = R_(W-2) + R_(W-1) + 2^(c-1) T_(W-1),  weight 2^(c (W-2)).
+// HC is the curve policy the fold runs on: the fast 64-bit-limb host field for G1, the generic
+// rr29 code otherwise.
+template <class HC> struct FoldTerm { int ex; const Proj<HC>* pt; };
+
 template <class HC>
-Proj<HC> fold_generic(const std::vector<Proj<HC>>& hw, int W, int c, int u) {
-    auto dbl_n = [](Proj<HC> a, int k) { for (int d = 0; d < k; d++) a = proj_dbl<HC>(a); return a; };
+Proj<HC> fold_terms(FoldTerm<HC>* t, int nt) {   // sum pt * 2^ex
+    for (int a = 1; a < nt; a++) for (int b = a; b > 0 && t[b].ex > t[b - 1].ex; b--) { FoldTerm<HC> x = t[b]; t[b] = t[b - 1]; t[b - 1] = x; }
+    Proj<HC> val = *t[0].pt;
+    int cur = t[0].ex;
+    for (int k = 1; k < nt; k++) {
+        for (int d = 0; d < cur - t[k].ex; d++) val = proj_dbl<HC>(val);
+        cur = t[k].ex;
+        val = proj_add<HC>(val, *t[k].pt);
+    }
+    for (int d = 0; d < cur; d++) val = proj_dbl<HC>(val);
+    return val;
+}
+
+template <class HC>
+Proj<HC> fold_generic(const std::vector<Proj<HC>>& hw, int W, int c, int u, int top_unsigned) {
+    auto PT = [&](int which, int w, int k) { return &hw[(size_t)(which * W + w) * 3 + k]; };
+    auto window_terms = [&](int w, FoldTerm<HC>* t) {
+        t[0] = FoldTerm<HC>{u + 6, PT(0, w, 1)};   // PW
+        t[1] = FoldTerm<HC>{u, PT(0, w, 2)};       // PS
+        t[2] = FoldTerm<HC>{6, PT(1, w, 0)};       // PA
+        t[3] = FoldTerm<HC>{0, PT(2, w, 0)};       // PB
+    };
     Proj<HC> acc = proj_zero<HC>();
-    for (int w = W - 1; w >= 0; w--) {
-        const Proj<HC>* pts[5] = {&acc, &hw[(size_t)(0 * W + w) * 3 + 1], &hw[(size_t)(0 * W + w) * 3 + 2],
-                                  &hw[(size_t)(1 * W + w) * 3 + 0], &hw[(size_t)(2 * W + w) * 3 + 0]};
-        int ex[5] = {c, u + 6, u, 6, 0};
-        int idx[5] = {0, 1, 2, 3, 4};
-        for (int a = 1; a < 5; a++) for (int b = a; b > 0 && ex[idx[b]] > ex[idx[b - 1]]; b--) { int t = idx[b]; idx[b] = idx[b - 1]; idx[b - 1] = t; }
-        Proj<HC> val = *pts[idx[0]];
-        int cur = ex[idx[0]];
-        for (int k = 1; k < 5; k++) {
-            val = dbl_n(val, cur - ex[idx[k]]);
-            cur = ex[idx[k]];
-            val = proj_add<HC>(val, *pts[idx[k]]);
-        }
+    int w = W - 1;
+    if (top_unsigned) {
+        FoldTerm<HC> t[9];
+        window_terms(W - 2, t);
+        window_terms(W - 1, t + 4);
+        t[8] = FoldTerm<HC>{c - 1, PT(0, W - 1, 0)};   // 2^(c-1) * T_(W-1)
+        acc = fold_terms<HC>(t, 9);
+        w = W - 3;
+    }
+    for (; w >= 0; w--) {
+        FoldTerm<HC> t[5];
+        window_terms(w, t);
+        t[4] = FoldTerm<HC>{c, &acc};
+        Proj<HC> val = fold_terms<HC>(t, 5);
         acc = val;
     }
     if (proj_is_zero<HC>(acc)) acc = proj_zero<HC>();   // canonical (0, 1, 0) like the reference's zero()
@@ -120,17 +155,17 @@ Proj<HC> fold_generic(const std::vector<Proj<HC>>& hw, int W, int c, int u) {
 }
 
 template <class C>
-void fold_windows(const std::vector<Proj<C>>& hw, int W, int c, int u, uint64_t* out_xyz) {
+void fold_windows(const std::vector<Proj<C>>& hw, int W, int c, int u, int top_unsigned, uint64_t* out_xyz) {
     typedef typename HostCurveOf<C>::type HC;
     if constexpr (HostCurveOf<C>::fast) {
         std::vector<Proj<HC>> h64(hw.size());
         for (size_t i = 0; i < hw.size(); i++) {   // internal -> ABI Montgomery limbs == host representation
             proj_to_abi_host<C>(reinterpret_cast<uint64_t*>(&h64[i]), hw[i]);
         }
-        Proj<HC> acc = fold_generic<HC>(h64, W, c, u);
+        Proj<HC> acc = fold_generic<HC>(h64, W, c, u, top_unsigned);
         memcpy(out_xyz, &acc, sizeof(acc));
     } else {
-        Proj<C> acc = fold_generic<C>(hw, W, c, u);
+        Proj<C> acc = fold_generic<C>(hw, W, c, u, top_unsigned);
         proj_to_abi_host<C>(out_xyz, acc);
     }
 }
@@ -146,7 +181,9 @@ int msm_run(BasesBase* h, const void* d_scalars, size_t n_scalars, uint64_t* out
         return GH_OK;
     }
     const int c = auto_window(n);
-    const int W = 753 / c + 1;
+    // after sign folding the scalar magnitudes are below 2^752 (msm_kernels.h, digits kernel)
+    const int W = 752 / c + 1;
+    const int top_unsigned = (752 % c == 0 && W >= 2) ? 1 : 0;
     const uint32_t nb = (1u << (c - 1)) + 1;
     const size_t total = (size_t)W * nb;
     static const int env_L1 = getenv("GH_REDUCE_L") ? atoi(getenv("GH_REDUCE_L")) : 0;
@@ -167,8 +204,14 @@ int msm_run(BasesBase* h, const void* d_scalars, size_t n_scalars, uint64_t* out
         HIPCHK(hipMalloc((void**)&salts, sizeof(hs)));
         HIPCHK(hipMemcpy(salts, hs, sizeof(hs), hipMemcpyHostToDevice));
     }
-    // heavy threshold: 4x the mean bucket load, within [128, MSM_MAX_HEAVY_THRESHOLD]
+    // Heavy threshold.  Buckets are walked longest first, one per thread at ~78 us per addition
+    // (2 waves / SIMD), so a bucket of s entries is free as long as s * 78 us stays well inside the
+    // kernel's own duration (~ W n / 1.65e9 s); beyond that it would be the tail, and is split.
     uint32_t heavy_thr = (uint32_t)((4 * n) >> (c - 1));
+    {
+        const uint32_t by_duration = (uint32_t)((double)W * (double)n * 3.1e-6);
+        if (heavy_thr < by_duration) heavy_thr = by_duration;
+    }
     if (heavy_thr < 128) heavy_thr = 128;
     if (heavy_thr > (uint32_t)MSM_MAX_HEAVY_THRESHOLD) heavy_thr = MSM_MAX_HEAVY_THRESHOLD;
     const size_t max_heavy = ((size_t)W * n) / (heavy_thr + 1) + 1;          // buckets with > thr entries
@@ -204,7 +247,7 @@ int msm_run(BasesBase* h, const void* d_scalars, size_t n_scalars, uint64_t* out
     HIPCHK(hipMemsetAsync(counts, 0, total * 4, st));
     HIPCHK(hipMemsetAsync(size_hist, 0, MSM_SIZE_BINS * 4, st));
     hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
-                       (const uint32_t*)d_scalars, (const uint8_t*)h->d_inf, n, c, W, nb, digits, counts);
+                       (const uint32_t*)d_scalars, (const uint8_t*)h->d_inf, n, c, W, nb, top_unsigned, scalar_modulus<C>(), digits, counts);
     HIPCHK(hipGetLastError());
     TRACE("digits done")
     if ((rc = device_scan(counts, starts, total, "scan_tmp"))) return rc;
@@ -278,7 +321,7 @@ int msm_run(BasesBase* h, const void* d_scalars, size_t n_scalars, uint64_t* out
     //   acc*2^c + R_w = (((acc*2^(c-u-6) + PW)*2^6 + PS)*2^(u-6) + PA)*2^6 + PB        (c >= u + 6)
     int u = 6;
     while ((1 << (u - 6)) < L1) u++;
-    fold_windows<C>(hw, W, c, u, out_xyz);
+    fold_windows<C>(hw, W, c, u, top_unsigned, out_xyz);
     TRACE("fold done")
 #undef TRACE
     auto t_end = std::chrono::steady_clock::now();

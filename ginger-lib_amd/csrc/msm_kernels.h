@@ -102,14 +102,26 @@ static __device__ __forceinline__ uint32_t wave_agg_inc(uint32_t* base, uint32_t
 }
 
 // ---------------------------------------------------------------- 1. digits + histogram
-// scalars: n x 24 words canonical.  digits[w * n + i] = signed digit (0 = no contribution).
+// scalars: n x 24 words canonical (< r).  digits[w * n + i] = signed digit (0 = no contribution).
 // counts[w * nb + |d|] += 1, nb = 2^(c-1) + 1 (slot 0 unused).
-// Signed recoding: v = bits(s, wc, c) + carry; if v > 2^(c-1): d = v - 2^c, carry = 1.
-// num_windows = floor(753 / c) + 1 guarantees the top window never carries out.
-// (reference digit rule, unsigned: variable_base.rs:43-50.)
+//
+// (a) sign folding: s > r/2 is replaced by r - s with the base negated (s P = (r - s)(-P)), so the
+//     magnitude is below 2^752 and bit 752 never needs a window.
+// (b) signed recoding of the c-bit windows: v = bits(s, wc, c) + carry; if v > 2^(c-1):
+//     d = v - 2^c, carry = 1  (reference digit rule, unsigned: variable_base.rs:43-50).
+// (c) the top window.  num_windows = floor(752 / c) + 1.  If c does not divide 752 the last window
+//     holds the 752 mod c leftover bits plus the carry and never carries out.  If c divides 752
+//     (c = 16: 47 * 16) the last window would hold nothing but the carry -- one bucket with n/2
+//     entries.  Instead (top_unsigned) window W-2, the top real one, is taken UNSIGNED:
+//     v <= 0.885 * 2^c + 1 is filed under slot v of window W-2 if v <= 2^(c-1), else under slot
+//     v - 2^(c-1) of window W-1, which thereby is "region b" of window W-2 (same window weight,
+//     slot offset 2^(c-1): the host adds 2^(c-1) * sum(region b), msm_impl.h fold_windows).
+struct MsmModulus { uint32_t w[24]; };
+
 static __global__ void __launch_bounds__(256)
 msm_digits_kernel(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ infinity, size_t n, int c,
-                  int num_windows, uint32_t nb, int32_t* __restrict__ digits, uint32_t* __restrict__ counts) {
+                  int num_windows, uint32_t nb, int top_unsigned, MsmModulus r,
+                  int32_t* __restrict__ digits, uint32_t* __restrict__ counts) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = i < n;
     uint32_t s[25];
@@ -120,9 +132,26 @@ msm_digits_kernel(const uint32_t* __restrict__ scalars, const uint8_t* __restric
 #pragma unroll
         for (int k = 0; k < 6; k++) { uint4 v = q[k]; s[4 * k] = v.x; s[4 * k + 1] = v.y; s[4 * k + 2] = v.z; s[4 * k + 3] = v.w; }
     }
+    // (a) t = r - s;  negate if t < s
+    uint32_t t[24];
+    uint32_t bw = 0;
+    bool lt = false;   // t < s, decided by the most significant differing word
+#pragma unroll
+    for (int k = 0; k < 24; k++) {
+        uint64_t x = (uint64_t)r.w[k] - s[k] - bw;
+        t[k] = (uint32_t)x;
+        bw = (uint32_t)(x >> 32) & 1u;
+        if (t[k] != s[k]) lt = t[k] < s[k];
+    }
+    const bool sneg = lt && bw == 0;   // bw != 0 would mean s > r (non-canonical input): leave as is
+    if (sneg) {
+#pragma unroll
+        for (int k = 0; k < 24; k++) s[k] = t[k];
+    }
     const bool skip = !valid || (infinity != nullptr && infinity[i] != 0);
-    const uint32_t half = 1u << (c - 1), full_mask = (c == 32) ? 0xFFFFFFFFu : ((1u << c) - 1);
+    const uint32_t half = 1u << (c - 1), full_mask = (1u << c) - 1;
     uint32_t carry = 0;
+    int32_t d_next = 0;   // region-b digit of the top_unsigned scheme, emitted for window W-1
     for (int w = 0; w < num_windows; w++) {
         const int bit = w * c;
         uint32_t v = 0;
@@ -133,7 +162,13 @@ msm_digits_kernel(const uint32_t* __restrict__ scalars, const uint8_t* __restric
         }
         v += carry;
         int32_t d;
-        if (v > half) { d = (int32_t)v - (int32_t)(1u << c); carry = 1; } else { d = (int32_t)v; carry = 0; }
+        if (top_unsigned && w == num_windows - 2) {
+            if (v > half) { d = 0; d_next = (int32_t)(v - half); } else { d = (int32_t)v; }
+            carry = 0;
+        } else if (top_unsigned && w == num_windows - 1) {
+            d = d_next;
+        } else if (v > half) { d = (int32_t)v - (int32_t)(1u << c); carry = 1; } else { d = (int32_t)v; carry = 0; }
+        if (sneg) d = -d;
         if (skip) d = 0;
         if (valid) digits[(size_t)w * n + i] = d;
         const uint32_t mag = d < 0 ? (uint32_t)(-d) : (uint32_t)d;

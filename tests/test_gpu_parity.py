@@ -164,6 +164,30 @@ def test_msm_vs_oracle(gpu, curve, sizes):
             assert not got[24 * k:].any()
 
 
+@pytest.mark.parametrize("curve", ["mnt4753_g1", "mnt6753_g1"])
+def test_msm_window_sizes_vs_oracle(gpu, curve):
+    """every digit-extraction regime: c | 752 (unsigned two-region top window: 4, 8, 16), leftover top
+    windows of different fill (5, 13, 15, 18), scalars around r/2 (sign folding) and the extremes"""
+    C = pyref.CURVES[curve]
+    r = C.order
+    rng = pyref.Rng(31)
+    n = 96
+    pts = S.chain_points(C, n, rng)
+    scal = [rng.field_elem(r) for _ in range(n)]
+    scal[:10] = [0, 1, 2, r - 1, r - 2, (r - 1) // 2, (r + 1) // 2, (r + 3) // 2, 1 << 751, (1 << 752) + 12345]
+    b, inf = S.bases_array(C, pts)
+    s = S.scalar_array(scal)
+    exp = S.oracle_msm(curve, b, inf, s, 16)
+    try:
+        for c in (4, 5, 8, 13, 15, 16, 18):
+            gpu.msm_set_window(c)
+            got = gpu.VariableBaseMSM.multi_scalar_mul(curve, b, s, inf)
+            assert gpu.msm_last_timing()["window_bits"] == c
+            assert affine_eq(gpu, curve, got, exp), (curve, c)
+    finally:
+        gpu.msm_set_window(0)
+
+
 def test_msm_unequal_lengths_and_resident(gpu):
     curve = "mnt4753_g1"
     C = pyref.CURVES[curve]
