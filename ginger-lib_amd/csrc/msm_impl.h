@@ -215,7 +215,8 @@ int msm_run(BasesBase* h, const void* d_scalars, size_t n_scalars, uint64_t* out
     if (heavy_thr < 128) heavy_thr = 128;
     if (heavy_thr > (uint32_t)MSM_MAX_HEAVY_THRESHOLD) heavy_thr = MSM_MAX_HEAVY_THRESHOLD;
     const size_t max_heavy = ((size_t)W * n) / (heavy_thr + 1) + 1;          // buckets with > thr entries
-    const size_t max_chunks = ((size_t)W * n) / MSM_HEAVY_CHUNK + max_heavy + 1;
+    const uint32_t heavy_chunk = heavy_thr;                                  // chunk = a bucket of threshold size
+    const size_t max_chunks = ((size_t)W * n) / heavy_chunk + max_heavy + 1;
     int32_t* digits; uint32_t *counts, *starts, *cursor, *sorted, *order, *size_hist, *size_cursor, *chunk_start, *plan;
     Proj<C>*buckets, *seg_out, *win_out, *partials;
     int rc;
@@ -257,7 +258,7 @@ int msm_run(BasesBase* h, const void* d_scalars, size_t n_scalars, uint64_t* out
     if ((rc = device_scan(size_hist, size_cursor, MSM_SIZE_BINS, "scan_tmp2"))) return rc;
     hipLaunchKernelGGL(msm_size_scatter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, counts, total, heavy_thr, size_cursor, order);
     hipLaunchKernelGGL(msm_heavy_plan_kernel, dim3(1), dim3(1), 0, st, (const uint32_t*)size_hist, (const uint32_t*)counts,
-                       (const uint32_t*)order, chunk_start, plan);
+                       (const uint32_t*)order, heavy_chunk, chunk_start, plan);
     hipLaunchKernelGGL(msm_scatter_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)W), dim3(256), 0, st,
                        (const int32_t*)digits, n, W, nb, cursor, sorted);
     HIPCHK(hipGetLastError());
@@ -269,29 +270,29 @@ int msm_run(BasesBase* h, const void* d_scalars, size_t n_scalars, uint64_t* out
     const uint32_t n_heavy = hplan[0], n_chunks = hplan[1];
     if (n_heavy > max_heavy || n_chunks > max_chunks) { g_err = "internal: heavy-bucket plan out of range"; return GH_E_HIP; }
     const size_t lds_wave = 64 * sizeof(Proj<C>);
+    partials = nullptr;
+    if (n_heavy > 0 && (rc = pool_get("partials", (size_t)n_chunks * sizeof(Proj<C>), (void**)&partials))) return rc;
+    // 2 waves / SIMD (256 VGPRs, 184 B scratch) measured 29.3 ms vs 34.6 ms for 1 wave (297 registers) at 2^20
+    static const int acc_waves = getenv("GH_ACC_WAVES") ? atoi(getenv("GH_ACC_WAVES")) : 2;
     HIPCHK(hipEventRecord(g.ev[2], st));
     {
-        size_t rest = total - n_heavy;
-        static const int acc_waves = getenv("GH_ACC_WAVES") ? atoi(getenv("GH_ACC_WAVES")) : 2;  // measured: 29.3 ms vs 34.6 ms at 2^20
+        // one launch: the chunks of the heavy buckets first, then every other bucket, longest first
+        const size_t tasks = (size_t)n_chunks + (total - n_heavy);
         if (acc_waves >= 2 && C::F::DEG == 1)
-            hipLaunchKernelGGL((msm_accumulate_kernel<C, (C::F::DEG == 1 ? 2 : 1)>), dim3((unsigned)((rest + 255) / 256)), dim3(256), 0, st,
+            hipLaunchKernelGGL((msm_accumulate_kernel<C, (C::F::DEG == 1 ? 2 : 1)>), dim3((unsigned)((tasks + 255) / 256)), dim3(256), 0, st,
                                (const Aff<C>*)h->d_points, (const uint32_t*)sorted, (const uint32_t*)starts,
-                               (const uint32_t*)counts, (const uint32_t*)order, n_heavy, (uint32_t)total,
-                               (const Aff<C>*)salts, buckets);
+                               (const uint32_t*)counts, (const uint32_t*)order, (uint32_t)total, (const Aff<C>*)salts, buckets,
+                               (const uint32_t*)chunk_start, n_heavy, n_chunks, heavy_chunk, partials);
         else
-            hipLaunchKernelGGL((msm_accumulate_kernel<C, 1>), dim3((unsigned)((rest + 255) / 256)), dim3(256), 0, st,
+            hipLaunchKernelGGL((msm_accumulate_kernel<C, 1>), dim3((unsigned)((tasks + 255) / 256)), dim3(256), 0, st,
                                (const Aff<C>*)h->d_points, (const uint32_t*)sorted, (const uint32_t*)starts,
-                               (const uint32_t*)counts, (const uint32_t*)order, n_heavy, (uint32_t)total,
-                               (const Aff<C>*)salts, buckets);
+                               (const uint32_t*)counts, (const uint32_t*)order, (uint32_t)total, (const Aff<C>*)salts, buckets,
+                               (const uint32_t*)chunk_start, n_heavy, n_chunks, heavy_chunk, partials);
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(g.ev[3], st));
     TRACE("accumulate done")
-    if (n_heavy > 0) {
-        if ((rc = pool_get("partials", (size_t)n_chunks * sizeof(Proj<C>), (void**)&partials))) return rc;
-        hipLaunchKernelGGL((msm_heavy_chunk_kernel<C>), dim3(n_chunks), dim3(64), lds_wave, st, (const Aff<C>*)h->d_points,
-                           (const uint32_t*)sorted, (const uint32_t*)starts, (const uint32_t*)counts, (const uint32_t*)order,
-                           (const uint32_t*)chunk_start, n_heavy, partials);
+    if (n_heavy > 0) {   // one wave per heavy bucket adds its chunk sums
         hipLaunchKernelGGL((msm_heavy_combine_kernel<C>), dim3(n_heavy), dim3(64), lds_wave, st, (const Proj<C>*)partials,
                            (const uint32_t*)order, (const uint32_t*)chunk_start, buckets);
         HIPCHK(hipGetLastError());

@@ -14,9 +14,10 @@
 //   4. msm_accumulate_kernel one thread per bucket walks its list: gather the base (internal
 //                            layout, 208 B for G1), conditional negate, projective mixed add
 //                            (ec29.h proj_madd, 11 Fp-mul).  ~94 % of all work (as in the reference).
-//      msm_heavy_*_kernel    buckets longer than the heavy threshold (4x the mean) are cut into
-//                            chunks summed by one wave each, then combined (skewed real-world
-//                            witnesses -- many equal small scalars -- and the top window).
+//      chunk mode + msm_heavy_combine_kernel: buckets longer than the heavy threshold are cut into
+//                            chunks that the same kernel sums like ordinary buckets, then combined
+//                            (skewed real-world witnesses -- many equal small scalars -- and
+//                            sparsely populated top windows).
 //   5. msm_reduce1/2_kernel  sum_b b * B_b per window without the reference's per-window inversion:
 //                            each lane serially folds L consecutive buckets (running sum), then the
 //                            64 lanes of the wave combine their (run, weighted) pairs with a
@@ -33,7 +34,6 @@ namespace gh {
 constexpr int MSM_REDUCE_L = 16;         // buckets folded serially per lane in reduce level 1
 constexpr int MSM_MAX_HEAVY_THRESHOLD = 1024;  // upper bound of the run-time heavy threshold
 constexpr int MSM_SIZE_BINS = MSM_MAX_HEAVY_THRESHOLD + 2;
-constexpr int MSM_HEAVY_CHUNK = 512;          // entries of a heavy bucket summed by one wave
 
 // ---------------------------------------------------------------- generic point load / store
 template <class C> __device__ __forceinline__ Aff<C> ld_aff(const Aff<C>* p) {
@@ -210,13 +210,13 @@ msm_size_scatter_kernel(const uint32_t* counts, size_t total, uint32_t heavy_thr
 
 // plan[0] = n_heavy, plan[1] = total number of chunks; chunk_start[h] for h in [0, n_heavy]
 static __global__ void msm_heavy_plan_kernel(const uint32_t* size_hist, const uint32_t* counts, const uint32_t* order,
-                                             uint32_t* chunk_start, uint32_t* plan) {
+                                             uint32_t chunk, uint32_t* chunk_start, uint32_t* plan) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const uint32_t n_heavy = size_hist[0];
     uint32_t run = 0;
     for (uint32_t h = 0; h < n_heavy; h++) {
         chunk_start[h] = run;
-        run += (counts[order[h]] + MSM_HEAVY_CHUNK - 1) / MSM_HEAVY_CHUNK;
+        run += (counts[order[h]] + chunk - 1) / chunk;
     }
     chunk_start[n_heavy] = run;
     plan[0] = n_heavy;
@@ -252,13 +252,30 @@ template <class C, int WAVES>
 __global__ void __launch_bounds__(256, WAVES)
 msm_accumulate_kernel(const Aff<C>* __restrict__ bases, const uint32_t* __restrict__ sorted,
                       const uint32_t* __restrict__ starts, const uint32_t* __restrict__ counts,
-                      const uint32_t* __restrict__ order, uint32_t first, uint32_t total,
-                      const Aff<C>* __restrict__ salts, Proj<C>* __restrict__ buckets) {
+                      const uint32_t* __restrict__ order, uint32_t total,
+                      const Aff<C>* __restrict__ salts, Proj<C>* __restrict__ buckets,
+                      const uint32_t* __restrict__ chunk_start, uint32_t n_heavy, uint32_t n_chunks, uint32_t chunk,
+                      Proj<C>* __restrict__ partials) {
     typedef typename C::F F;
-    uint32_t t = first + blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= total) return;
-    const uint32_t g = order[t];
-    const uint32_t beg = starts[g], cnt = counts[g];
+    // task list: [0, n_chunks) chunks of the heavy buckets (the longest tasks, scheduled first),
+    //            then the buckets order[n_heavy ..] by descending size
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_chunks + (total - n_heavy)) return;
+    uint32_t beg, cnt;
+    Proj<C>* dst;
+    if (t >= n_chunks) {         // one whole bucket per thread
+        const uint32_t g = order[n_heavy + (t - n_chunks)];
+        beg = starts[g]; cnt = counts[g];
+        dst = buckets + g;
+    } else {                     // chunk t: a slice of `chunk` entries of heavy bucket order[h] -> partials[t]
+        uint32_t lo = 0, hi = n_heavy;   // largest h with chunk_start[h] <= t
+        while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (chunk_start[mid] <= t) lo = mid; else hi = mid; }
+        const uint32_t g = order[lo], j = t - chunk_start[lo];
+        beg = starts[g] + j * chunk;
+        cnt = counts[g] - j * chunk;
+        if (cnt > chunk) cnt = chunk;
+        dst = partials + t;
+    }
     Proj<C> acc = proj_zero<C>();
     uint32_t k = 0;
     int phase = 0, salt_id = 0;     // phase 0: list entry k; 1: +S; 2: entry k again; 3: -S
@@ -298,7 +315,7 @@ msm_accumulate_kernel(const Aff<C>* __restrict__ bases, const uint32_t* __restri
         }
         if (phase == 0 || phase == 3) { k++; phase = 0; } else phase++;
     }
-    st_proj<C>(buckets + g, acc);
+    st_proj<C>(dst, acc);
 }
 
 // wave-level sum of one projective point per lane through LDS; result valid in lane 0.
@@ -314,37 +331,10 @@ __device__ __forceinline__ Proj<C> wave_tree_sum(Proj<C> v, Proj<C>* sh, int lan
     return v;
 }
 
-// Heavy buckets (skewed scalars; the top window, whose digits are only 0/1/2): every chunk of
-// MSM_HEAVY_CHUNK entries is summed by one wave (lanes stride through the chunk, then a tree
-// through LDS); a second launch adds the chunk sums of each heavy bucket the same way.
-template <class C>
-__global__ void __launch_bounds__(64, 2)
-msm_heavy_chunk_kernel(const Aff<C>* __restrict__ bases, const uint32_t* __restrict__ sorted,
-                       const uint32_t* __restrict__ starts, const uint32_t* __restrict__ counts,
-                       const uint32_t* __restrict__ order, const uint32_t* __restrict__ chunk_start, uint32_t n_heavy,
-                       Proj<C>* __restrict__ partials) {
-    typedef typename C::F F;
-    extern __shared__ uint32_t lds_raw[];
-    Proj<C>* sh = reinterpret_cast<Proj<C>*>(lds_raw);
-    const int lane = threadIdx.x;
-    // binary search: largest h with chunk_start[h] <= blockIdx.x
-    uint32_t lo = 0, hi = n_heavy;
-    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (chunk_start[mid] <= blockIdx.x) lo = mid; else hi = mid; }
-    const uint32_t g = order[lo];
-    const uint32_t j = blockIdx.x - chunk_start[lo];
-    const uint32_t beg = starts[g] + j * MSM_HEAVY_CHUNK;
-    uint32_t cnt = counts[g] - j * MSM_HEAVY_CHUNK;
-    if (cnt > (uint32_t)MSM_HEAVY_CHUNK) cnt = MSM_HEAVY_CHUNK;
-    Proj<C> acc = proj_zero<C>();
-    for (uint32_t k = lane; k < cnt; k += 64) {
-        const uint32_t e = sorted[beg + k];
-        Aff<C> q = ld_aff<C>(bases + (e & 0x7FFFFFFFu));
-        if (e >> 31) q.y = F::neg(q.y);
-        acc = proj_madd_call<C>(acc, q);
-    }
-    acc = wave_tree_sum<C>(acc, sh, lane);
-    if (lane == 0) st_proj<C>(partials + blockIdx.x, acc);
-}
+// Heavy buckets (skewed scalars, sparsely populated top windows) are cut into chunks of heavy_thr
+// entries that the accumulation kernel sums like ordinary buckets (chunk mode above, into
+// partials[]); this kernel then adds the chunk sums of each heavy bucket: lanes stride through
+// them, then a tree through LDS.
 template <class C>
 __global__ void __launch_bounds__(64, 2)
 msm_heavy_combine_kernel(const Proj<C>* __restrict__ partials, const uint32_t* __restrict__ order,
