@@ -128,6 +128,19 @@ def main():
     madds = tm_last["accumulate_madds"]
     fpmul_rate = madds * 11 / (acc_avg_ms * 1e-3)
 
+    # HBM traffic per launch of the dominant kernels: PMC counters collected with rocprofv3 in separate
+    # passes on this same command (profiles/r01_pmc_traffic.json); null if that file is absent or the
+    # workload differs from the profiled one (2^20 pairs / 2^24 points).
+    traffic_acc = traffic_ntt = None
+    try:
+        tr = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        if args.log_n == 20:
+            traffic_acc = tr["msm_accumulate_kernel"]["fetch_bytes_per_launch"] + tr["msm_accumulate_kernel"]["write_bytes_per_launch"]
+        if args.ntt_log_n == 24:
+            traffic_ntt = 3 * (tr["ntt_pass_kernel"]["fetch_bytes_per_launch"] + tr["ntt_pass_kernel"]["write_bytes_per_launch"])
+    except Exception:
+        pass
+
     out = {
         "metric": "MNT4-753 G1 MSM scalar-muls/sec + 2^n NTT ms at 1/2/4/8 MI355X",
         "value": value,
@@ -145,7 +158,8 @@ def main():
                    "pairs_per_gpu": n, "window_bits": tm_last["window_bits"], "num_windows": tm_last["num_windows"],
                    "distinct_bases": pool_n, "parallelism": "pairs sharded by rank, 1 all-gather of partial sums" if world > 1 else "single GPU"},
         "roofline": {"kernel": "msm_accumulate_kernel<Mnt4G1>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_acc,
+                     "traffic_note": "FETCH_SIZE + WRITE_SIZE bytes per launch from profiles/r01_pmc_traffic.json (every base is re-read once per window: W x 208 B gathers; plus register-spill scratch)",
                      "avg_launch_ms": acc_avg_ms, "algorithmic_bytes_per_launch": alg_bytes,
                      "note": "integer-VALU bound by construction (SURVEY 8d): see valu"},
         "valu": {"achieved_fpmul_per_s": fpmul_rate, "peak_fpmul_per_s": FPMUL_PEAK_PER_S, "frac": fpmul_rate / FPMUL_PEAK_PER_S,
@@ -174,7 +188,7 @@ def main():
                       "transforms": "fft, ifft, coset_fft, coset_ifft cycled; device resident, in place",
                       "roofline": {"kernel": "ntt_pass_kernel<P6> (all passes of one transform)", "bound": "hbm",
                                    "achieved": nb / (ntt_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                   "frac": nb / (ntt_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                   "frac": nb / (ntt_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic_ntt,
                                    "algorithmic_bytes_per_transform": nb}}
 
     # ---- CPU baseline: the oracle (restated reference algorithm, C++) on the host cores, bounded sample

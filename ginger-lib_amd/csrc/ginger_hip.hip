@@ -70,10 +70,14 @@ int device_scan(const uint32_t* in, uint32_t* out, size_t n, const char* tmpname
 // accumulate work (n * ceil(754/c) additions) against bucket-reduction work (2^(c-1) buckets per
 // window), what matters is how full the TOP window is -- c = 13 (58 * 13 = 754), 18 (42 * 18 = 756),
 // 19 and 21 leave no sparsely populated top window whose few buckets become over-long.
-int auto_window(size_t n) {
+int auto_window(size_t n, int deg) {
     if (g.window_override > 0) return g.window_override;
     int lg = 0;
     while (((size_t)1 << (lg + 1)) <= n) lg++;
+    if (deg > 1) {   // G2: the host fold and the reduction weigh more per window -> fewer, larger windows
+        int c = lg - 4;
+        return c < 4 ? 4 : (c > 20 ? 20 : c);
+    }
     if (lg >= 23) return 19;
     if (lg >= 21) return 18;
     if (lg >= 19) return 16;
@@ -220,9 +224,9 @@ int gh_msm_set_window(int c) {
     g.window_override = c;
     return GH_OK;
 }
-int gh_msm_get_window(gh_curve_t, size_t n) {
+int gh_msm_get_window(gh_curve_t curve, size_t n) {
     std::lock_guard<std::mutex> lk(g_mu);
-    return auto_window(n);
+    return auto_window(n, curve == GH_MNT4753_G2 ? 2 : (curve == GH_MNT6753_G2 ? 3 : 1));
 }
 int gh_msm_last_timing(gh_msm_timing_t* out) {
     std::lock_guard<std::mutex> lk(g_mu);

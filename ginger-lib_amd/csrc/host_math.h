@@ -29,11 +29,11 @@ template <class P> inline Fp host_fp_pow_pm2(const Fp& a) {
 template <class P> inline Fp host_fp_inv(const Fp& a) { return host_fp_pow_pm2<P>(a); }
 
 template <class F> struct HostInv;
-template <class P> struct HostInv<F1<P>> {
+template <class P, bool I> struct HostInv<F1<P, I>> {
     static Fp inv(const Fp& a) { return host_fp_inv<P>(a); }
 };
-template <class P, int NR> struct HostInv<F2<P, NR>> {
-    typedef typename F2<P, NR>::T T;
+template <class P, int NR, bool I> struct HostInv<F2<P, NR, I>> {
+    typedef Fp2T T;
     // (a0 + a1 X)^-1 = (a0 - a1 X) / (a0^2 - NR a1^2)          (fp2.rs inverse)
     static T inv(const T& a) {
         Fp n = fp_sub<P>(fp_sqr<P>(a.c0), fp_mul_small<P, NR>(fp_sqr<P>(a.c1)));
@@ -41,8 +41,8 @@ template <class P, int NR> struct HostInv<F2<P, NR>> {
         return T{fp_mul<P>(a.c0, ni), fp_neg<P>(fp_mul<P>(a.c1, ni))};
     }
 };
-template <class P, int NR> struct HostInv<F3<P, NR>> {
-    typedef typename F3<P, NR>::T T;
+template <class P, int NR, bool I> struct HostInv<F3<P, NR, I>> {
+    typedef Fp3T T;
     // norm-based inverse in Fp[X]/(X^3 - NR)                    (fp3.rs inverse)
     static T inv(const T& a) {
         Fp t0 = fp_sqr<P>(a.c0), t1 = fp_sqr<P>(a.c1), t2 = fp_sqr<P>(a.c2);

@@ -180,7 +180,7 @@ int msm_run(BasesBase* h, const void* d_scalars, size_t n_scalars, uint64_t* out
         g.last_msm = tm;
         return GH_OK;
     }
-    const int c = auto_window(n);
+    const int c = auto_window(n, C::F::DEG);
     // after sign folding the scalar magnitudes are below 2^752 (msm_kernels.h, digits kernel)
     const int W = 752 / c + 1;
     const int top_unsigned = (752 % c == 0 && W >= 2) ? 1 : 0;
@@ -278,8 +278,8 @@ int msm_run(BasesBase* h, const void* d_scalars, size_t n_scalars, uint64_t* out
     {
         // one launch: the chunks of the heavy buckets first, then every other bucket, longest first
         const size_t tasks = (size_t)n_chunks + (total - n_heavy);
-        if (acc_waves >= 2 && C::F::DEG == 1)
-            hipLaunchKernelGGL((msm_accumulate_kernel<C, (C::F::DEG == 1 ? 2 : 1)>), dim3((unsigned)((tasks + 255) / 256)), dim3(256), 0, st,
+        if (acc_waves >= 2)
+            hipLaunchKernelGGL((msm_accumulate_kernel<C, 2>), dim3((unsigned)((tasks + 255) / 256)), dim3(256), 0, st,
                                (const Aff<C>*)h->d_points, (const uint32_t*)sorted, (const uint32_t*)starts,
                                (const uint32_t*)counts, (const uint32_t*)order, (uint32_t)total, (const Aff<C>*)salts, buckets,
                                (const uint32_t*)chunk_start, n_heavy, n_chunks, heavy_chunk, partials);

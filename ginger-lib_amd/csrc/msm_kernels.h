@@ -18,13 +18,13 @@
 //                            chunks that the same kernel sums like ordinary buckets, then combined
 //                            (skewed real-world witnesses -- many equal small scalars -- and
 //                            sparsely populated top windows).
-//   5. msm_reduce1/2_kernel  sum_b b * B_b per window without the reference's per-window inversion:
-//                            each lane serially folds L consecutive buckets (running sum), then the
-//                            64 lanes of the wave combine their (run, weighted) pairs with a
-//                            log-step suffix scan + tree reduction through LDS ("wavefront-wide
-//                            bucket reduction"); a second launch combines the waves of a window.
-//   6. window fold           753 dependent doublings: latency-bound, done on the host
-//                            (ginger_hip.hip: fold_windows_host) from the W window sums.
+//   5. msm_wave_reduce_kernel  sum_b b * B_b per window without the reference's per-window inversion
+//                            and without doublings: "wave programs" whose every step is one
+//                            projective addition from a single inlined call site (serial sums per
+//                            lane, then tree / suffix scan / tree across the 64 lanes through LDS:
+//                            the wavefront-wide bucket reduction); two launches.
+//   6. window fold           ~750 dependent doublings: latency-bound, done on the host
+//                            (msm_impl.h fold_windows) with the reduction's powers of two merged in.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "ec29.h"
@@ -302,16 +302,34 @@ msm_accumulate_kernel(const Aff<C>* __restrict__ bases, const uint32_t* __restri
                 phase = 1;
                 continue;
             }
+            // operation order chosen to keep at most seven field elements live (register budget 256);
+            // the scheduling fences make hipcc keep that order instead of hoisting products
+#if defined(__HIP_DEVICE_COMPILE__)
+#define GH_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define GH_FENCE()
+#endif
             u = F::sub(u, acc.y);
-            typename F::T uu = F::sqr(u);
             v = F::sub(v, acc.x);
+            GH_FENCE();
             typename F::T vv = F::sqr(v);
-            typename F::T vvv = F::mul(v, vv);
-            typename F::T r = F::mul(vv, acc.x);
-            typename F::T a = F::sub(F::sub(F::mul(uu, acc.z), vvv), F::dbl(r));
-            acc.x = F::mul(v, a);
-            acc.y = F::sub(F::mul(u, F::sub(r, a)), F::mul(vvv, acc.y));
+            GH_FENCE();
+            typename F::T r = F::mul(vv, acc.x);        // acc.x dead
+            GH_FENCE();
+            typename F::T vvv = F::mul(v, vv);          // vv dead
+            GH_FENCE();
+            typename F::T uu = F::sqr(u);
+            GH_FENCE();
+            typename F::T a = F::sub(F::sub(F::mul(uu, acc.z), vvv), F::dbl(r));   // uu dead
+            GH_FENCE();
+            acc.x = F::mul(v, a);                       // v dead
+            GH_FENCE();
+            typename F::T t1 = F::mul(u, F::sub(r, a)); // u, r, a dead
+            GH_FENCE();
+            acc.y = F::sub(t1, F::mul(vvv, acc.y));
+            GH_FENCE();
             acc.z = F::mul(vvv, acc.z);
+#undef GH_FENCE
         }
         if (phase == 0 || phase == 3) { k++; phase = 0; } else phase++;
     }
@@ -378,8 +396,11 @@ template <class C> struct WaveReduceIn {
 };
 
 // branch-free projective addition with selects for the infinity cases; same = (p == q as points)
+template <class C> struct ReduceField { typedef typename C::F type; };          // G1: inlined products
+template <> struct ReduceField<Mnt4G2> { typedef Mnt4G2::FC type; };                 // towers: out of line (code size)
+template <> struct ReduceField<Mnt6G2> { typedef Mnt6G2::FC type; };
 template <class C> __device__ __forceinline__ Proj<C> proj_add_sel(const Proj<C>& p, const Proj<C>& q, bool& same) {
-    typedef typename C::F F;
+    typedef typename ReduceField<C>::type F;
     const bool pz = F::is_zero(p.z), qz = F::is_zero(q.z);
     typename F::T y1z2 = F::mul(p.y, q.z);
     typename F::T x1z2 = F::mul(p.x, q.z);

@@ -44,7 +44,7 @@ extern std::string g_err;
 int ensure_init();
 int pool_get(const char* name, size_t bytes, void** out);
 int device_scan(const uint32_t* in, uint32_t* out, size_t n, const char* tmpname);
-int auto_window(size_t n);
+int auto_window(size_t n, int deg);
 
 #define HIPCHK(call)                                                                         \
     do {                                                                                     \
