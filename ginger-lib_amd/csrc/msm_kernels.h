@@ -276,6 +276,12 @@ msm_accumulate_kernel(const Aff<C>* __restrict__ bases, const uint32_t* __restri
         if (cnt > chunk) cnt = chunk;
         dst = partials + t;
     }
+    // Y1 is needed at the start (u = y2 Z1 - Y1) and at the very end (Y3 = ... - vvv Y1) of an
+    // addition; in between it is parked in LDS (G1 only, 26 KiB per block, word-major so lanes
+    // hit distinct banks) -- that is the difference between fitting the 256-register budget and
+    // spilling to scratch.
+    constexpr bool PARK = (F::DEG == 1);
+    __shared__ uint32_t park[PARK ? NL : 1][PARK ? 256 : 1];
     Proj<C> acc = proj_zero<C>();
     uint32_t k = 0;
     int phase = 0, salt_id = 0;     // phase 0: list entry k; 1: +S; 2: entry k again; 3: -S
@@ -311,6 +317,11 @@ msm_accumulate_kernel(const Aff<C>* __restrict__ bases, const uint32_t* __restri
 #endif
             u = F::sub(u, acc.y);
             v = F::sub(v, acc.x);
+            if constexpr (PARK) {
+                const uint32_t* yw = reinterpret_cast<const uint32_t*>(&acc.y);
+#pragma unroll
+                for (int w = 0; w < NL; w++) park[w][threadIdx.x] = yw[w];
+            }
             GH_FENCE();
             typename F::T vv = F::sqr(v);
             GH_FENCE();
@@ -326,7 +337,13 @@ msm_accumulate_kernel(const Aff<C>* __restrict__ bases, const uint32_t* __restri
             GH_FENCE();
             typename F::T t1 = F::mul(u, F::sub(r, a)); // u, r, a dead
             GH_FENCE();
-            acc.y = F::sub(t1, F::mul(vvv, acc.y));
+            typename F::T y1 = acc.y;
+            if constexpr (PARK) {
+                uint32_t* yw = reinterpret_cast<uint32_t*>(&y1);
+#pragma unroll
+                for (int w = 0; w < NL; w++) yw[w] = park[w][threadIdx.x];
+            }
+            acc.y = F::sub(t1, F::mul(vvv, y1));
             GH_FENCE();
             acc.z = F::mul(vvv, acc.z);
 #undef GH_FENCE
