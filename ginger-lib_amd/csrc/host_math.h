@@ -124,10 +124,71 @@ template <class P> struct HF1 {
         return acc;
     }
 };
+// towers over the 64-bit-limb host field, same formulas as F2 / F3 (fp2.rs:389-400, :128-144;
+// fp3.rs:453-477, :165-185), for the window fold of G2 results
+template <class B, int NR> struct HF2 {
+    struct T { H64 c0, c1; };
+    static constexpr int DEG = 2;
+    static T zero() { return T{B::zero(), B::zero()}; }
+    static T one() { return T{B::one(), B::zero()}; }
+    static T add(const T& a, const T& b) { return T{B::add(a.c0, b.c0), B::add(a.c1, b.c1)}; }
+    static T sub(const T& a, const T& b) { return T{B::sub(a.c0, b.c0), B::sub(a.c1, b.c1)}; }
+    static T dbl(const T& a) { return T{B::dbl(a.c0), B::dbl(a.c1)}; }
+    static T neg(const T& a) { return T{B::neg(a.c0), B::neg(a.c1)}; }
+    static T mul(const T& a, const T& b) {
+        H64 v0 = B::mul(a.c0, b.c0), v1 = B::mul(a.c1, b.c1);
+        H64 s = B::mul(B::add(a.c0, a.c1), B::add(b.c0, b.c1));
+        return T{B::add(v0, B::mul_small(v1, NR)), B::sub(B::sub(s, v0), v1)};
+    }
+    static T sqr(const T& a) {
+        H64 v0 = B::sub(a.c0, a.c1), v3 = B::sub(a.c0, B::mul_small(a.c1, NR)), v2 = B::mul(a.c0, a.c1);
+        H64 t = B::mul(v0, v3);
+        return T{B::add(B::add(t, v2), B::mul_small(v2, NR)), B::dbl(v2)};
+    }
+    static bool is_zero(const T& a) { return B::is_zero(a.c0) && B::is_zero(a.c1); }
+    static bool eq(const T& a, const T& b) { return B::eq(a.c0, b.c0) && B::eq(a.c1, b.c1); }
+};
+template <class B, int NR> struct HF3 {
+    struct T { H64 c0, c1, c2; };
+    static constexpr int DEG = 3;
+    static T zero() { return T{B::zero(), B::zero(), B::zero()}; }
+    static T one() { return T{B::one(), B::zero(), B::zero()}; }
+    static T add(const T& a, const T& b) { return T{B::add(a.c0, b.c0), B::add(a.c1, b.c1), B::add(a.c2, b.c2)}; }
+    static T sub(const T& a, const T& b) { return T{B::sub(a.c0, b.c0), B::sub(a.c1, b.c1), B::sub(a.c2, b.c2)}; }
+    static T dbl(const T& a) { return T{B::dbl(a.c0), B::dbl(a.c1), B::dbl(a.c2)}; }
+    static T neg(const T& a) { return T{B::neg(a.c0), B::neg(a.c1), B::neg(a.c2)}; }
+    static T mul(const T& A, const T& Bv) {
+        const H64 &a = Bv.c0, &b = Bv.c1, &c = Bv.c2, &d = A.c0, &e = A.c1, &f = A.c2;
+        H64 ad = B::mul(d, a), be = B::mul(e, b), cf = B::mul(f, c);
+        H64 x = B::sub(B::sub(B::mul(B::add(e, f), B::add(b, c)), be), cf);
+        H64 y = B::sub(B::sub(B::mul(B::add(d, e), B::add(a, b)), ad), be);
+        H64 z = B::sub(B::add(B::sub(B::mul(B::add(d, f), B::add(a, c)), ad), be), cf);
+        return T{B::add(ad, B::mul_small(x, NR)), B::add(y, B::mul_small(cf, NR)), z};
+    }
+    static T sqr(const T& A) {
+        const H64 &a = A.c0, &b = A.c1, &c = A.c2;
+        H64 s0 = B::sqr(a), ab = B::mul(a, b), s1 = B::dbl(ab), s2 = B::sqr(B::add(B::sub(a, b), c));
+        H64 bc = B::mul(b, c), s3 = B::dbl(bc), s4 = B::sqr(c);
+        return T{B::add(s0, B::mul_small(s3, NR)), B::add(s1, B::mul_small(s4, NR)),
+                 B::sub(B::sub(B::add(B::add(s1, s2), s3), s0), s4)};
+    }
+    static bool is_zero(const T& a) { return B::is_zero(a.c0) && B::is_zero(a.c1) && B::is_zero(a.c2); }
+    static bool eq(const T& a, const T& b) { return B::eq(a.c0, b.c0) && B::eq(a.c1, b.c1) && B::eq(a.c2, b.c2); }
+};
+struct HostMnt4G2 {   // a' = (26, 0): curves/mnt4753/g2.rs:113-118
+    typedef HF2<HF1<P4>, 13> F; typedef F FC;
+    static F::T mul_by_a(const F::T& z) { return F::T{HF1<P4>::mul_small(z.c0, 26), HF1<P4>::mul_small(z.c1, 26)}; }
+};
+struct HostMnt6G2 {   // a' = (0, 0, 11): curves/mnt6753/g2.rs:149-155
+    typedef HF3<HF1<P6>, 11> F; typedef F FC;
+    static F::T mul_by_a(const F::T& z) { return F::T{HF1<P6>::mul_small(z.c1, 121), HF1<P6>::mul_small(z.c2, 121), HF1<P6>::mul_small(z.c0, 11)}; }
+};
 struct HostMnt4G1 { typedef HF1<P4> F; typedef HF1<P4> FC; static H64 mul_by_a(const H64& z) { return HF1<P4>::dbl(z); } };
 struct HostMnt6G1 { typedef HF1<P6> F; typedef HF1<P6> FC; static H64 mul_by_a(const H64& z) { return HF1<P6>::mul_small(z, 11); } };
 template <class C> struct HostCurveOf { typedef C type; static constexpr bool fast = false; };
 template <> struct HostCurveOf<Mnt4G1> { typedef HostMnt4G1 type; static constexpr bool fast = true; };
 template <> struct HostCurveOf<Mnt6G1> { typedef HostMnt6G1 type; static constexpr bool fast = true; };
+template <> struct HostCurveOf<Mnt4G2> { typedef HostMnt4G2 type; static constexpr bool fast = true; };
+template <> struct HostCurveOf<Mnt6G2> { typedef HostMnt6G2 type; static constexpr bool fast = true; };
 
 }  // namespace gh

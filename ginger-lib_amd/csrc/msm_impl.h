@@ -4,6 +4,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <chrono>
+#include <type_traits>
 #include <vector>
 #include "runtime.h"
 #include "msm_kernels.h"
@@ -278,6 +279,16 @@ int msm_run(BasesBase* h, const void* d_scalars, size_t n_scalars, uint64_t* out
     {
         // one launch: the chunks of the heavy buckets first, then every other bucket, longest first
         const size_t tasks = (size_t)n_chunks + (total - n_heavy);
+        static const bool no_pair = getenv("GH_NO_PAIR") != nullptr;
+        if constexpr (std::is_same<C, Mnt4G2>::value) {
+            if (!no_pair) {   // Fq2: two lanes per task (msm_kernels.h 4b)
+                hipLaunchKernelGGL((msm_accumulate_pair_kernel<C, P4, 13>), dim3((unsigned)((2 * tasks + 255) / 256)), dim3(256), 0, st,
+                                   (const Aff<C>*)h->d_points, (const uint32_t*)sorted, (const uint32_t*)starts,
+                                   (const uint32_t*)counts, (const uint32_t*)order, (uint32_t)total, (const Aff<C>*)salts, buckets,
+                                   (const uint32_t*)chunk_start, n_heavy, n_chunks, heavy_chunk, partials);
+            }
+        }
+        if (!(std::is_same<C, Mnt4G2>::value && !no_pair)) {
         if (acc_waves >= 2)
             hipLaunchKernelGGL((msm_accumulate_kernel<C, 2>), dim3((unsigned)((tasks + 255) / 256)), dim3(256), 0, st,
                                (const Aff<C>*)h->d_points, (const uint32_t*)sorted, (const uint32_t*)starts,
@@ -288,6 +299,7 @@ int msm_run(BasesBase* h, const void* d_scalars, size_t n_scalars, uint64_t* out
                                (const Aff<C>*)h->d_points, (const uint32_t*)sorted, (const uint32_t*)starts,
                                (const uint32_t*)counts, (const uint32_t*)order, (uint32_t)total, (const Aff<C>*)salts, buckets,
                                (const uint32_t*)chunk_start, n_heavy, n_chunks, heavy_chunk, partials);
+        }
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(g.ev[3], st));

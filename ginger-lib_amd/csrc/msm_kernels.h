@@ -59,6 +59,22 @@ template <class C> __device__ __forceinline__ void st_proj(Proj<C>* p, const Pro
     for (int i = 0; i < (int)(sizeof(Proj<C>) / 8); i++) q[i] = s[i];
 }
 
+#ifndef GH_LD_ST_FP
+#define GH_LD_ST_FP
+__device__ __forceinline__ Fp ld_fp(const Fp* p) {
+    Fp r;
+    const uint2* q = reinterpret_cast<const uint2*>(p);
+#pragma unroll
+    for (int i = 0; i < NL / 2; i++) { uint2 v = q[i]; r.l[2 * i] = v.x; r.l[2 * i + 1] = v.y; }
+    return r;
+}
+__device__ __forceinline__ void st_fp(Fp* p, const Fp& a) {
+    uint2* q = reinterpret_cast<uint2*>(p);
+#pragma unroll
+    for (int i = 0; i < NL / 2; i++) q[i] = make_uint2(a.l[2 * i], a.l[2 * i + 1]);
+}
+#endif
+
 // ---------------------------------------------------------------- bases: ABI -> internal layout
 // in: n x (2 * DEG * 24) words (x || y, Montgomery 2^768); out: n x Aff<C> (internal 2^754)
 template <class C>
@@ -351,6 +367,153 @@ msm_accumulate_kernel(const Aff<C>* __restrict__ bases, const uint32_t* __restri
         if (phase == 0 || phase == 3) { k++; phase = 0; } else phase++;
     }
     st_proj<C>(dst, acc);
+}
+
+// ---------------------------------------------------------------- 4b. G2 over Fq2: lane-pair formulation
+// An Fq2 element (c0, c1) lives in TWO adjacent lanes: c0 in the even lane, c1 in the odd one, so a
+// G2 point costs each lane the registers of a G1 point and the kernel needs neither out-of-line
+// products nor scratch (the call-based Fq2 kernel moved ~16 KB of scratch per mixed addition
+// and was bandwidth bound).  Products use the schoolbook split, two Fp products per lane:
+//   even lane: c0 = a0 b0 + NR a1 b1        odd lane: c1 = a1 b0 + a0 b1
+// with the partner's coefficients fetched by a lane swap (26 DPP moves per operand).
+// 22 Fp-product times per mixed addition and lane pair, against 31 on one lane -- but in registers.
+template <class P, int NR> struct F2S {
+    typedef Fp T;
+    static constexpr int DEG = 1;   // per-lane footprint (enables the LDS parking of Y1)
+    static __device__ __forceinline__ bool odd() { return (threadIdx.x & 1u) != 0; }
+    static __device__ __forceinline__ T swap(const T& a) {
+        T r;
+#pragma unroll
+        for (int i = 0; i < NL; i++) r.l[i] = (uint32_t)__shfl_xor((int)a.l[i], 1);
+        return r;
+    }
+    static __device__ __forceinline__ T sel(bool c, const T& x, const T& y) {   // c ? x : y
+        T r;
+#pragma unroll
+        for (int i = 0; i < NL; i++) r.l[i] = c ? x.l[i] : y.l[i];
+        return r;
+    }
+    static __device__ __forceinline__ T zero() { return fp_zero(); }
+    static __device__ __forceinline__ T one() { return odd() ? fp_zero() : fp_one<P>(); }
+    static __device__ __forceinline__ T add(const T& a, const T& b) { return fp_add<P>(a, b); }
+    static __device__ __forceinline__ T sub(const T& a, const T& b) { return fp_sub<P>(a, b); }
+    static __device__ __forceinline__ T dbl(const T& a) { return fp_dbl<P>(a); }
+    static __device__ __forceinline__ T neg(const T& a) { return fp_neg<P>(a); }
+    static __device__ __forceinline__ T mul(const T& a, const T& b) {
+        const bool o = odd();
+        const T ao = swap(a), bo = swap(b);
+        const T t1 = fp_mul<P>(a, sel(o, bo, b));     // even: a0 b0      odd: a1 b0
+        const T t2 = fp_mul<P>(ao, sel(o, b, bo));    // even: a1 b1      odd: a0 b1
+        return fp_add<P>(t1, sel(o, t2, fp_mul_small<P, NR>(t2)));
+    }
+    static __device__ __forceinline__ T sqr(const T& a) { return mul(a, a); }
+    static __device__ __forceinline__ bool is_zero(const T& a) {
+        const int z = fp_is_zero(a) ? 1 : 0;
+        return (z & __shfl_xor(z, 1)) != 0;
+    }
+    static __device__ __forceinline__ bool eq(const T& a, const T& b) {
+        const int z = fp_eq(a, b) ? 1 : 0;
+        return (z & __shfl_xor(z, 1)) != 0;
+    }
+};
+
+// Same task list and addition as msm_accumulate_kernel, two lanes per task.
+template <class C, class P, int NR>
+__global__ void __launch_bounds__(256, 1)
+msm_accumulate_pair_kernel(const Aff<C>* __restrict__ bases, const uint32_t* __restrict__ sorted,
+                           const uint32_t* __restrict__ starts, const uint32_t* __restrict__ counts,
+                           const uint32_t* __restrict__ order, uint32_t total,
+                           const Aff<C>* __restrict__ salts, Proj<C>* __restrict__ buckets,
+                           const uint32_t* __restrict__ chunk_start, uint32_t n_heavy, uint32_t n_chunks, uint32_t chunk,
+                           Proj<C>* __restrict__ partials) {
+    typedef F2S<P, NR> F;
+    const uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) >> 1;
+    const int comp = threadIdx.x & 1;
+    const uint32_t ntasks = n_chunks + (total - n_heavy);
+    const bool live = t < ntasks;          // both lanes of a pair agree; idle pairs still take part in the swaps
+    uint32_t beg = 0, cnt = 0;
+    Proj<C>* dst = buckets;
+    if (live) {
+        if (t >= n_chunks) {
+            const uint32_t g = order[n_heavy + (t - n_chunks)];
+            beg = starts[g]; cnt = counts[g];
+            dst = buckets + g;
+        } else {
+            uint32_t lo = 0, hi = n_heavy;
+            while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (chunk_start[mid] <= t) lo = mid; else hi = mid; }
+            const uint32_t g = order[lo], j = t - chunk_start[lo];
+            beg = starts[g] + j * chunk;
+            cnt = counts[g] - j * chunk;
+            if (cnt > chunk) cnt = chunk;
+            dst = partials + t;
+        }
+    }
+    __shared__ uint32_t park[NL][256];
+    // this lane's coefficient of a stored Fq2: element e of an Aff / Proj is {c0, c1} -> Fp index 2 e + comp
+    auto ld_comp = [&](const void* base, int e) { return ld_fp(reinterpret_cast<const Fp*>(base) + 2 * e + comp); };
+    Fp ax = fp_zero(), ay = F::one(), az = fp_zero();   // (0, 1, 0)
+    uint32_t k = 0;
+    int phase = 0, salt_id = 0;
+    uint32_t guard = 0;
+    // the loop condition must be uniform within a pair (it is: both lanes share cnt, k, phase)
+    while (k < cnt && guard < 4 * cnt + 8) {
+        guard++;
+        Fp qx, qy;
+        if (phase == 1 || phase == 3) {
+            qx = ld_comp(salts + salt_id, 0);
+            qy = ld_comp(salts + salt_id, 1);
+            if (phase == 3) qy = F::neg(qy);
+        } else {
+            const uint32_t e = sorted[beg + k];
+            const Aff<C>* b = bases + (e & 0x7FFFFFFFu);
+            qx = ld_comp(b, 0);
+            qy = ld_comp(b, 1);
+            if (e >> 31) qy = F::neg(qy);
+        }
+        if (F::is_zero(az)) {
+            ax = qx; ay = qy; az = F::one();
+        } else {
+            Fp v = F::mul(qx, az);
+            Fp u = F::mul(qy, az);
+            if (phase == 0 && F::eq(u, ay) && F::eq(v, ax)) {
+                salt_id = F::eq(qx, ld_comp(salts, 0)) ? 1 : 0;
+                phase = 1;
+                continue;
+            }
+            u = F::sub(u, ay);
+            v = F::sub(v, ax);
+#pragma unroll
+            for (int w = 0; w < NL; w++) park[w][threadIdx.x] = ay.l[w];
+            __builtin_amdgcn_sched_barrier(0);
+            Fp vv = F::sqr(v);
+            __builtin_amdgcn_sched_barrier(0);
+            Fp r = F::mul(vv, ax);
+            __builtin_amdgcn_sched_barrier(0);
+            Fp vvv = F::mul(v, vv);
+            __builtin_amdgcn_sched_barrier(0);
+            Fp uu = F::sqr(u);
+            __builtin_amdgcn_sched_barrier(0);
+            Fp a = F::sub(F::sub(F::mul(uu, az), vvv), F::dbl(r));
+            __builtin_amdgcn_sched_barrier(0);
+            ax = F::mul(v, a);
+            __builtin_amdgcn_sched_barrier(0);
+            Fp t1 = F::mul(u, F::sub(r, a));
+            __builtin_amdgcn_sched_barrier(0);
+            Fp y1;
+#pragma unroll
+            for (int w = 0; w < NL; w++) y1.l[w] = park[w][threadIdx.x];
+            ay = F::sub(t1, F::mul(vvv, y1));
+            __builtin_amdgcn_sched_barrier(0);
+            az = F::mul(vvv, az);
+        }
+        if (phase == 0 || phase == 3) { k++; phase = 0; } else phase++;
+    }
+    if (live) {
+        Fp* o = reinterpret_cast<Fp*>(dst);
+        st_fp(o + 0 + comp, ax);
+        st_fp(o + 2 + comp, ay);
+        st_fp(o + 4 + comp, az);
+    }
 }
 
 // wave-level sum of one projective point per lane through LDS; result valid in lane 0.

@@ -36,6 +36,8 @@ constexpr int NTT_LOG_TILE = 9;
 constexpr int NTT_MAX_TILE = 1 << NTT_LOG_TILE;
 constexpr int NTT_MAX_LOGR = 8;
 
+#ifndef GH_LD_ST_FP
+#define GH_LD_ST_FP
 __device__ __forceinline__ Fp ld_fp(const Fp* p) {
     Fp r;
     const uint2* q = reinterpret_cast<const uint2*>(p);
@@ -48,6 +50,7 @@ __device__ __forceinline__ void st_fp(Fp* p, const Fp& a) {
 #pragma unroll
     for (int i = 0; i < NL / 2; i++) q[i] = make_uint2(a.l[2 * i], a.l[2 * i + 1]);
 }
+#endif
 // ABI element (24 words) <-> registers, 16-byte accesses
 __device__ __forceinline__ Fp ld_abi_raw(const uint32_t* p) {
     uint32_t w[24];

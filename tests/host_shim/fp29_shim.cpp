@@ -87,6 +87,15 @@ void t_h64_op(int field, int op, const uint64_t* a, const uint64_t* b, uint64_t*
 void t_h64_ec(int field, int op, const uint64_t* p, const uint64_t* q, uint64_t* out) {
     if (field == 4) h64_ec<HostMnt4G1>(op, p, q, out); else h64_ec<HostMnt6G1>(op, p, q, out);
 }
+// curve ids as in ginger_hip.h (0..3): add / double on the host fold fields, incl. the G2 towers
+void t_h64_ec_curve(int curve, int op, const uint64_t* p, const uint64_t* q, uint64_t* out) {
+    switch (curve) {
+        case 0: h64_ec<HostMnt4G1>(op, p, q, out); break;
+        case 1: h64_ec<HostMnt4G2>(op, p, q, out); break;
+        case 2: h64_ec<HostMnt6G1>(op, p, q, out); break;
+        case 3: h64_ec<HostMnt6G2>(op, p, q, out); break;
+    }
+}
 void t_fp_op(int field, int op, const uint32_t* a, const uint32_t* b, uint32_t* out) {
     if (field == 4) fp_op<P4>(op, a, b, out); else fp_op<P6>(op, a, b, out);
 }

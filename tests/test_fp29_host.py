@@ -146,3 +146,32 @@ def test_host_fold_field(shim, fid, F, curve):
         assert aff(out) == C.add(A, B)
     shim.t_h64_ec(fid, 1, proj(P, 3), proj(P, 3), out)
     assert aff(out) == C.add(P, P)
+
+
+@pytest.mark.parametrize("cid,name", [(1, "mnt4753_g2"), (3, "mnt6753_g2")])
+def test_host_fold_towers(shim, cid, name):
+    """G2 add / double on the 64-bit-limb host towers (host_math.h HF2 / HF3) used by the window fold"""
+    C = pyref.CURVES[name]
+    F, E, k = C.F, C.E, C.deg
+    U64 = ctypes.c_uint64
+
+    def proj(Pt, z):
+        if Pt is None:
+            X, Y, Z = E.zero(), E.one(), E.zero()
+        else:
+            X, Y, Z = E.mul(Pt[0], z), E.mul(Pt[1], z), z
+        limbs = pyref.ext_to_abi(F, X) + pyref.ext_to_abi(F, Y) + pyref.ext_to_abi(F, Z)
+        return (U64 * (36 * k))(*limbs)
+
+    def aff(out):
+        v = [int(x) for x in out]
+        return C.proj_to_affine(pyref.ext_from_abi(F, v[:12 * k], k), pyref.ext_from_abi(F, v[12 * k:24 * k], k),
+                                pyref.ext_from_abi(F, v[24 * k:], k))
+    P, Q = C.mul(4242, C.G), C.mul(99991, C.G)
+    z1, z2 = tuple(range(3, 3 + k)), tuple(range(11, 11 + k))
+    out = (U64 * (36 * k))()
+    for A, B in ((P, Q), (P, P), (P, C.neg(P)), (None, Q), (P, None)):
+        shim.t_h64_ec_curve(cid, 0, proj(A, z1), proj(B, z2), out)
+        assert aff(out) == C.add(A, B)
+    shim.t_h64_ec_curve(cid, 1, proj(P, z1), proj(P, z1), out)
+    assert aff(out) == C.add(P, P)
