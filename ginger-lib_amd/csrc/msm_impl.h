@@ -279,16 +279,23 @@ int msm_run(BasesBase* h, const void* d_scalars, size_t n_scalars, uint64_t* out
     {
         // one launch: the chunks of the heavy buckets first, then every other bucket, longest first
         const size_t tasks = (size_t)n_chunks + (total - n_heavy);
-        static const bool no_pair = getenv("GH_NO_PAIR") != nullptr;
-        if constexpr (std::is_same<C, Mnt4G2>::value) {
-            if (!no_pair) {   // Fq2: two lanes per task (msm_kernels.h 4b)
-                hipLaunchKernelGGL((msm_accumulate_pair_kernel<C, P4, 13>), dim3((unsigned)((2 * tasks + 255) / 256)), dim3(256), 0, st,
+        static const bool no_split = getenv("GH_NO_SPLIT") != nullptr;
+        // Only Fq2 is instantiated: the Fq3 lane-triple instance (F3S) is correct by construction but hipcc
+        // needed more than half an hour to compile it (unified 512-register allocation), so MNT6 G2
+        // stays on the out-of-line path for now.
+        constexpr bool is_g2 = std::is_same<C, Mnt4G2>::value;
+        if constexpr (is_g2) {
+            if (!no_split) {   // Fq2 / Fq3: one coefficient per lane, 2 / 3 lanes per task (msm_kernels.h 4b)
+                typedef typename std::conditional<std::is_same<C, Mnt4G2>::value, F2S<P4, 13>, F3S<P6, 11>>::type FS;
+                constexpr int LANES = FS::LANES;
+                const size_t waves = (tasks + (64 / LANES) - 1) / (64 / LANES);
+                hipLaunchKernelGGL((msm_accumulate_split_kernel<C, FS, LANES>), dim3((unsigned)((waves * 64 + 255) / 256)), dim3(256), 0, st,
                                    (const Aff<C>*)h->d_points, (const uint32_t*)sorted, (const uint32_t*)starts,
                                    (const uint32_t*)counts, (const uint32_t*)order, (uint32_t)total, (const Aff<C>*)salts, buckets,
                                    (const uint32_t*)chunk_start, n_heavy, n_chunks, heavy_chunk, partials);
             }
         }
-        if (!(std::is_same<C, Mnt4G2>::value && !no_pair)) {
+        if (!(is_g2 && !no_split)) {
         if (acc_waves >= 2)
             hipLaunchKernelGGL((msm_accumulate_kernel<C, 2>), dim3((unsigned)((tasks + 255) / 256)), dim3(256), 0, st,
                                (const Aff<C>*)h->d_points, (const uint32_t*)sorted, (const uint32_t*)starts,

@@ -379,7 +379,8 @@ msm_accumulate_kernel(const Aff<C>* __restrict__ bases, const uint32_t* __restri
 // 22 Fp-product times per mixed addition and lane pair, against 31 on one lane -- but in registers.
 template <class P, int NR> struct F2S {
     typedef Fp T;
-    static constexpr int DEG = 1;   // per-lane footprint (enables the LDS parking of Y1)
+    static constexpr int DEG = 1;   // per-lane footprint
+    static constexpr int LANES = 2;
     static __device__ __forceinline__ bool odd() { return (threadIdx.x & 1u) != 0; }
     static __device__ __forceinline__ T swap(const T& a) {
         T r;
@@ -417,20 +418,70 @@ template <class P, int NR> struct F2S {
     }
 };
 
-// Same task list and addition as msm_accumulate_kernel, two lanes per task.
-template <class C, class P, int NR>
+// Fq3 = Fp[X]/(X^3 - NR) over lane triples (lanes 3g, 3g+1, 3g+2 hold c0, c1, c2; lane 63 of a wave
+// idles).  Schoolbook, three Fp products per lane:
+//   c_j = sum_{m <= j} a_(j-m) b_m + NR sum_{m > j} a_(j-m+3) b_m
+template <class P, int NR> struct F3S {
+    typedef Fp T;
+    static constexpr int DEG = 1;
+    static constexpr int LANES = 3;
+    static __device__ __forceinline__ int comp() { return (int)((threadIdx.x & 63u) % 3u); }
+    static __device__ __forceinline__ T rot(const T& a, int by) {   // coefficient held by lane (comp + by) mod 3 of this triple
+        const int lane = threadIdx.x & 63, j = lane % 3, src = lane - j + (j + by) % 3;
+        T r;
+#pragma unroll
+        for (int i = 0; i < NL; i++) r.l[i] = (uint32_t)__shfl((int)a.l[i], src);
+        return r;
+    }
+    static __device__ __forceinline__ T sel3(int j, const T& x0, const T& x1, const T& x2) {
+        T r;
+#pragma unroll
+        for (int i = 0; i < NL; i++) r.l[i] = j == 0 ? x0.l[i] : (j == 1 ? x1.l[i] : x2.l[i]);
+        return r;
+    }
+    static __device__ __forceinline__ T zero() { return fp_zero(); }
+    static __device__ __forceinline__ T one() { return comp() == 0 ? fp_one<P>() : fp_zero(); }
+    static __device__ __forceinline__ T add(const T& a, const T& b) { return fp_add<P>(a, b); }
+    static __device__ __forceinline__ T sub(const T& a, const T& b) { return fp_sub<P>(a, b); }
+    static __device__ __forceinline__ T dbl(const T& a) { return fp_dbl<P>(a); }
+    static __device__ __forceinline__ T neg(const T& a) { return fp_neg<P>(a); }
+    static __device__ __forceinline__ T mul(const T& a, const T& b) {
+        const int j = comp();
+        const T an = rot(a, 1), ap = rot(a, 2), bn = rot(b, 1), bp = rot(b, 2);
+        const T t1 = fp_mul<P>(a, sel3(j, b, bp, bn));
+        const T t2 = fp_mul<P>(ap, sel3(j, bn, b, bp));
+        const T t3 = fp_mul<P>(an, sel3(j, bp, bn, b));
+        // j = 0: t1 + NR (t2 + t3);  j = 1: t1 + t2 + NR t3;  j = 2: t1 + t2 + t3
+        const T s23 = fp_add<P>(t2, t3);
+        const T x = sel3(j, fp_mul_small<P, NR>(s23), fp_add<P>(t2, fp_mul_small<P, NR>(t3)), s23);
+        return fp_add<P>(t1, x);
+    }
+    static __device__ __forceinline__ T sqr(const T& a) { return mul(a, a); }
+    static __device__ __forceinline__ bool all3(bool z) {
+        const int lane = threadIdx.x & 63, j = lane % 3, b = lane - j;
+        const int v = z ? 1 : 0;
+        return (__shfl(v, b) & __shfl(v, b + 1) & __shfl(v, b + 2)) != 0;
+    }
+    static __device__ __forceinline__ bool is_zero(const T& a) { return all3(fp_is_zero(a)); }
+    static __device__ __forceinline__ bool eq(const T& a, const T& b) { return all3(fp_eq(a, b)); }
+};
+
+// Same task list and addition as msm_accumulate_kernel, LANES lanes per task (2: Fq2 pairs, 3: Fq3
+// triples; a wave carries 64 / LANES tasks, the remaining lane of a triple wave idles).
+template <class C, class F, int LANES>
 __global__ void __launch_bounds__(256, 1)
-msm_accumulate_pair_kernel(const Aff<C>* __restrict__ bases, const uint32_t* __restrict__ sorted,
+msm_accumulate_split_kernel(const Aff<C>* __restrict__ bases, const uint32_t* __restrict__ sorted,
                            const uint32_t* __restrict__ starts, const uint32_t* __restrict__ counts,
                            const uint32_t* __restrict__ order, uint32_t total,
                            const Aff<C>* __restrict__ salts, Proj<C>* __restrict__ buckets,
                            const uint32_t* __restrict__ chunk_start, uint32_t n_heavy, uint32_t n_chunks, uint32_t chunk,
                            Proj<C>* __restrict__ partials) {
-    typedef F2S<P, NR> F;
-    const uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) >> 1;
-    const int comp = threadIdx.x & 1;
+    constexpr uint32_t TPW = 64 / LANES;                       // tasks per wave
+    const uint32_t lane = threadIdx.x & 63u, wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t t = wave * TPW + lane / LANES;
+    const int comp = (int)(lane % LANES);
     const uint32_t ntasks = n_chunks + (total - n_heavy);
-    const bool live = t < ntasks;          // both lanes of a pair agree; idle pairs still take part in the swaps
+    const bool live = lane < TPW * LANES && t < ntasks;       // all lanes of a group agree
     uint32_t beg = 0, cnt = 0;
     Proj<C>* dst = buckets;
     if (live) {
@@ -449,13 +500,13 @@ msm_accumulate_pair_kernel(const Aff<C>* __restrict__ bases, const uint32_t* __r
         }
     }
     __shared__ uint32_t park[NL][256];
-    // this lane's coefficient of a stored Fq2: element e of an Aff / Proj is {c0, c1} -> Fp index 2 e + comp
-    auto ld_comp = [&](const void* base, int e) { return ld_fp(reinterpret_cast<const Fp*>(base) + 2 * e + comp); };
+    // this lane's coefficient: element e of an Aff / Proj is {c0, .., c_(LANES-1)} -> Fp index LANES e + comp
+    auto ld_comp = [&](const void* base, int e) { return ld_fp(reinterpret_cast<const Fp*>(base) + LANES * e + comp); };
     Fp ax = fp_zero(), ay = F::one(), az = fp_zero();   // (0, 1, 0)
     uint32_t k = 0;
     int phase = 0, salt_id = 0;
     uint32_t guard = 0;
-    // the loop condition must be uniform within a pair (it is: both lanes share cnt, k, phase)
+    // the loop condition is uniform within a lane group (its lanes share cnt, k, phase)
     while (k < cnt && guard < 4 * cnt + 8) {
         guard++;
         Fp qx, qy;
@@ -510,9 +561,9 @@ msm_accumulate_pair_kernel(const Aff<C>* __restrict__ bases, const uint32_t* __r
     }
     if (live) {
         Fp* o = reinterpret_cast<Fp*>(dst);
-        st_fp(o + 0 + comp, ax);
-        st_fp(o + 2 + comp, ay);
-        st_fp(o + 4 + comp, az);
+        st_fp(o + 0 * LANES + comp, ax);
+        st_fp(o + 1 * LANES + comp, ay);
+        st_fp(o + 2 * LANES + comp, az);
     }
 }
 
