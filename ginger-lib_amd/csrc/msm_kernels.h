@@ -468,8 +468,11 @@ template <class P, int NR> struct F3S {
 
 // Same task list and addition as msm_accumulate_kernel, LANES lanes per task (2: Fq2 pairs, 3: Fq3
 // triples; a wave carries 64 / LANES tasks, the remaining lane of a triple wave idles).
+#ifndef GH_SPLIT_WAVES
+#define GH_SPLIT_WAVES 1   // measured on Fq2: 58.0 ms at 1 wave/SIMD (512 registers) vs 61.1 ms at 2 (1.5 KB of spills)
+#endif
 template <class C, class F, int LANES>
-__global__ void __launch_bounds__(256, 1)
+__global__ void __launch_bounds__(256, GH_SPLIT_WAVES)
 msm_accumulate_split_kernel(const Aff<C>* __restrict__ bases, const uint32_t* __restrict__ sorted,
                            const uint32_t* __restrict__ starts, const uint32_t* __restrict__ counts,
                            const uint32_t* __restrict__ order, uint32_t total,

@@ -127,22 +127,31 @@ __global__ void __launch_bounds__(NTT_MAX_TILE / 2, 2) ntt_pass_kernel(NttPassAr
                 for (int w = 0; w < NL; w++) { a.l[w] = lds[w * E + ea]; b.l[w] = lds[w * E + eb]; }
             }
         }
+        // s = a + b is written out before the twiddle product of d = a - b is started, and scheduling
+        // fences keep hipcc from interleaving the two: the live set stays inside the 256-register budget.
         Fp s, d;
+        const bool to_lds = m < k - 1;
+        const int ea_w = (ta << log_c) + c, eb_w = (tb << log_c) + c;
         if (active) {
             s = fp_add<P>(a, b);
+            if (to_lds) {
+#pragma unroll
+                for (int w = 0; w < NL; w++) lds[w * E + ea_w] = s.l[w];
+            }
+            __builtin_amdgcn_sched_barrier(0);
             d = fp_sub<P>(a, b);
+            __builtin_amdgcn_sched_barrier(0);
             if (h > 1) {
                 uint32_t e = (uint32_t)(q & (h - 1)) << (A.log_n - (k - m));  // w_(2h)^i = w_N^(i N / 2h)
                 if (A.inverse) e = (N - e) & nmask;
                 d = fp_mul<P>(d, ld_fp(A.tw + e));
             }
-        }
-        if (m < k - 1) {
-            if (active) {
-                const int ea = (ta << log_c) + c, eb = (tb << log_c) + c;
+            if (to_lds) {
 #pragma unroll
-                for (int w = 0; w < NL; w++) { lds[w * E + ea] = s.l[w]; lds[w * E + eb] = d.l[w]; }
+                for (int w = 0; w < NL; w++) lds[w * E + eb_w] = d.l[w];
             }
+        }
+        if (to_lds) {
             __syncthreads();
         } else if (active) {
             const uint32_t jbase = ((j - kk) << k) + kk;
