@@ -85,7 +85,7 @@ template <class C, class F = typename C::F> GH_HD Proj<C> proj_madd(const Proj<C
     typename F::T a = F::sub(F::sub(F::mul(uu, p.z), vvv), F::dbl(r));
     Proj<C> o;
     o.x = F::mul(v, a);
-    o.y = F::sub(F::mul(u, F::sub(r, a)), F::mul(vvv, p.y));
+    o.y = F::mul_sub_mul(u, F::sub(r, a), vvv, p.y);
     o.z = F::mul(vvv, p.z);
     return o;
 }
@@ -106,7 +106,7 @@ template <class C, class F = typename C::F> GH_HD Proj<C> proj_add(const Proj<C>
     typename F::T a = F::sub(F::sub(F::mul(uu, z1z2), vvv), F::dbl(r));
     Proj<C> o;
     o.x = F::mul(v, a);
-    o.y = F::sub(F::mul(F::sub(r, a), u), F::mul(vvv, y1z2));
+    o.y = F::mul_sub_mul(F::sub(r, a), u, vvv, y1z2);
     o.z = F::mul(vvv, z1z2);
     return o;
 }

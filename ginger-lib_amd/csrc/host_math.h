@@ -118,6 +118,7 @@ template <class P> struct HF1 {
         return r;
     }
     static T sqr(const T& a) { return mul(a, a); }
+    static T mul_sub_mul(const T& a, const T& b, const T& c, const T& d) { return sub(mul(a, b), mul(c, d)); }
     static T mul_small(const T& a, int k) {   // k * a by double-and-add
         T acc = a; int top = 30; while (!((k >> top) & 1)) top--;
         for (int b = top - 1; b >= 0; b--) { acc = dbl(acc); if ((k >> b) & 1) acc = add(acc, a); }
@@ -145,6 +146,7 @@ template <class B, int NR> struct HF2 {
         H64 t = B::mul(v0, v3);
         return T{B::add(B::add(t, v2), B::mul_small(v2, NR)), B::dbl(v2)};
     }
+    static T mul_sub_mul(const T& a, const T& b, const T& c, const T& d) { return sub(mul(a, b), mul(c, d)); }
     static bool is_zero(const T& a) { return B::is_zero(a.c0) && B::is_zero(a.c1); }
     static bool eq(const T& a, const T& b) { return B::eq(a.c0, b.c0) && B::eq(a.c1, b.c1); }
 };
@@ -172,6 +174,7 @@ template <class B, int NR> struct HF3 {
         return T{B::add(s0, B::mul_small(s3, NR)), B::add(s1, B::mul_small(s4, NR)),
                  B::sub(B::sub(B::add(B::add(s1, s2), s3), s0), s4)};
     }
+    static T mul_sub_mul(const T& a, const T& b, const T& c, const T& d) { return sub(mul(a, b), mul(c, d)); }
     static bool is_zero(const T& a) { return B::is_zero(a.c0) && B::is_zero(a.c1) && B::is_zero(a.c2); }
     static bool eq(const T& a, const T& b) { return B::eq(a.c0, b.c0) && B::eq(a.c1, b.c1) && B::eq(a.c2, b.c2); }
 };

@@ -351,7 +351,7 @@ msm_accumulate_kernel(const Aff<C>* __restrict__ bases, const uint32_t* __restri
             GH_FENCE();
             acc.x = F::mul(v, a);                       // v dead
             GH_FENCE();
-            typename F::T t1 = F::mul(u, F::sub(r, a)); // u, r, a dead
+            typename F::T rma = F::sub(r, a);           // r, a dead
             GH_FENCE();
             typename F::T y1 = acc.y;
             if constexpr (PARK) {
@@ -359,7 +359,9 @@ msm_accumulate_kernel(const Aff<C>* __restrict__ bases, const uint32_t* __restri
 #pragma unroll
                 for (int w = 0; w < NL; w++) yw[w] = park[w][threadIdx.x];
             }
-            acc.y = F::sub(t1, F::mul(vvv, y1));
+            // (the dual product with one reduction, F::mul_sub_mul, was measured SLOWER here: its two
+            //  accumulators cost 360 B more spills per addition; 31.2 ms vs 28.8 ms at 2^20)
+            acc.y = F::sub(F::mul(u, rma), F::mul(vvv, y1));
             GH_FENCE();
             acc.z = F::mul(vvv, acc.z);
 #undef GH_FENCE
@@ -403,10 +405,10 @@ template <class P, int NR> struct F2S {
     static __device__ __forceinline__ T mul(const T& a, const T& b) {
         const bool o = odd();
         const T ao = swap(a), bo = swap(b);
-        const T t1 = fp_mul<P>(a, sel(o, bo, b));     // even: a0 b0      odd: a1 b0
-        const T t2 = fp_mul<P>(ao, sel(o, b, bo));    // even: a1 b1      odd: a0 b1
-        return fp_add<P>(t1, sel(o, t2, fp_mul_small<P, NR>(t2)));
+        // one dual product per lane:  even: a0 b0 + (NR a1) b1      odd: a1 b0 + a0 b1
+        return fp_mul2<P>(a, sel(o, bo, b), sel(o, ao, fp_mul_small<P, NR>(ao)), sel(o, b, bo));
     }
+    static __device__ __forceinline__ T mul_sub_mul(const T& a, const T& b, const T& c, const T& d) { return sub(mul(a, b), mul(c, d)); }
     static __device__ __forceinline__ T sqr(const T& a) { return mul(a, a); }
     static __device__ __forceinline__ bool is_zero(const T& a) {
         const int z = fp_is_zero(a) ? 1 : 0;
@@ -457,6 +459,7 @@ template <class P, int NR> struct F3S {
         return fp_add<P>(t1, x);
     }
     static __device__ __forceinline__ T sqr(const T& a) { return mul(a, a); }
+    static __device__ __forceinline__ T mul_sub_mul(const T& a, const T& b, const T& c, const T& d) { return sub(mul(a, b), mul(c, d)); }
     static __device__ __forceinline__ bool all3(bool z) {
         const int lane = threadIdx.x & 63, j = lane % 3, b = lane - j;
         const int v = z ? 1 : 0;
@@ -649,7 +652,7 @@ template <class C> __device__ __forceinline__ Proj<C> proj_add_sel(const Proj<C>
     typename F::T a = F::sub(F::sub(F::mul(uu, z1z2), vvv), F::dbl(r));
     Proj<C> o;
     o.x = F::mul(v, a);
-    o.y = F::sub(F::mul(F::sub(r, a), u), F::mul(vvv, y1z2));
+    o.y = F::mul_sub_mul(F::sub(r, a), u, vvv, y1z2);
     o.z = F::mul(vvv, z1z2);
     uint32_t* ow = reinterpret_cast<uint32_t*>(&o);
     const uint32_t* pw = reinterpret_cast<const uint32_t*>(&p);

@@ -80,7 +80,13 @@ template <class HC> static void h64_ec(int op, const uint64_t* p, const uint64_t
     memcpy(out, &r, sizeof r);
 }
 
+template <class P> static void fp_mul2_op(const uint32_t* a, const uint32_t* b, const uint32_t* c, const uint32_t* d, uint32_t* out) {
+    fp_pack(out, fp_mul2<P>(fp_unpack(a), fp_unpack(b), fp_unpack(c), fp_unpack(d)));
+}
 extern "C" {
+void t_fp_mul2(int field, const uint32_t* a, const uint32_t* b, const uint32_t* c, const uint32_t* d, uint32_t* out) {
+    if (field == 4) fp_mul2_op<P4>(a, b, c, d, out); else fp_mul2_op<P6>(a, b, c, d, out);
+}
 void t_h64_op(int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out) {
     if (field == 4) h64_op<P4>(op, a, b, out); else h64_op<P6>(op, a, b, out);
 }

@@ -54,6 +54,10 @@ def test_field_ops(shim, fid, F):
         for op, e in exp.items():
             shim.t_fp_op(fid, op, words(a), words(b), out)
             assert toint(out) == e, (op, it)
+        # dual product with one reduction: (a b + c d) 2^-754, extremes included
+        c, d = (p - 1, p - 1) if it < 4 else (rng.field_elem(p), rng.field_elem(p))
+        shim.t_fp_mul2(fid, words(a), words(b), words(c), words(d), out)
+        assert toint(out) == ((a * b + c * d) * RIinv) % p, it
 
 
 @pytest.mark.parametrize("cid,name", list(enumerate(("mnt4753_g1", "mnt4753_g2", "mnt6753_g1", "mnt6753_g2"))))
