@@ -29,7 +29,8 @@ FIELDS = {"mnt4753_fr": 0, "mnt6753_fr": 1}
 # every symbol include/ginger_hip.h declares (checked by load_library and by tests/test_abi.py)
 ABI_SYMBOLS = [
     "gh_init", "gh_shutdown", "gh_last_error", "gh_device_name",
-    "gh_msm", "gh_bases_upload", "gh_bases_free", "gh_bases_len", "gh_msm_resident", "gh_msm_resident_dev",
+    "gh_msm", "gh_bases_upload", "gh_bases_free", "gh_bases_len", "gh_bases_precompute", "gh_bases_precomputed_window",
+    "gh_msm_resident", "gh_msm_resident_dev",
     "gh_msm_set_window", "gh_msm_get_window", "gh_msm_last_timing",
     "gh_domain_supported", "gh_fft", "gh_fft_dev", "gh_vec_mul_dev", "gh_vec_sub_dev", "gh_vec_scale_dev",
     "gh_vec_mul", "gh_vec_scale", "gh_fft_last_kernel_ms", "gh_witness_map", "gh_witness_map_dev",
@@ -72,6 +73,8 @@ def load_library():
     lib.gh_bases_free.argtypes = [vp]
     lib.gh_bases_len.argtypes = [vp]
     lib.gh_bases_len.restype = sz
+    lib.gh_bases_precompute.argtypes = [vp, ci]
+    lib.gh_bases_precomputed_window.argtypes = [vp]
     lib.gh_msm_resident.argtypes = [vp, vp, sz, vp]
     lib.gh_msm_resident_dev.argtypes = [vp, vp, sz, vp]
     lib.gh_msm_set_window.argtypes = [ci]
@@ -173,6 +176,11 @@ class ResidentBases:
         _check(load_library().gh_bases_upload(CURVES[curve], _ptr(bases), _ptr(inf) if inf is not None else None, n,
                                                ctypes.byref(self.handle)))
         self.n = n
+
+    def precompute(self, window_bits=0):
+        """Build the per-key shift table (gh_bases_precompute); returns the window size used."""
+        _check(load_library().gh_bases_precompute(self.handle, int(window_bits)))
+        return load_library().gh_bases_precomputed_window(self.handle)
 
     def msm(self, scalars):
         scalars = _u64(scalars, 12)

@@ -176,9 +176,27 @@ int gh_bases_free(gh_bases_t handle) {
     if (!h || h->magic != 0x6768424au) { g_err = "bad bases handle"; return GH_E_BAD_HANDLE; }
     if (h->d_points) hipFree(h->d_points);
     if (h->d_inf) hipFree(h->d_inf);
+    if (h->d_table) hipFree(h->d_table);
     h->magic = 0;
     delete h;
     return GH_OK;
+}
+
+int gh_bases_precompute(gh_bases_t handle, int window_bits) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    BasesBase* h = reinterpret_cast<BasesBase*>(handle);
+    if (!h || h->magic != 0x6768424au) { g_err = "bad bases handle"; return GH_E_BAD_HANDLE; }
+    if (window_bits < 0 || window_bits == 1 || window_bits > 24) { g_err = "window must be 0 (auto) or in [2, 24]"; return GH_E_BAD_ARG; }
+    const MsmOps* ops = ops_of(h->curve);
+    if (!ops) return GH_E_BAD_ARG;
+    int rc = ensure_init();
+    if (rc) return rc;
+    return ops->precompute(h, window_bits);
+}
+
+int gh_bases_precomputed_window(gh_bases_t handle) {
+    BasesBase* h = reinterpret_cast<BasesBase*>(handle);
+    return (h && h->magic == 0x6768424au && h->d_table) ? h->pre_c : 0;
 }
 
 size_t gh_bases_len(gh_bases_t handle) {

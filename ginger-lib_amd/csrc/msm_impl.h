@@ -101,6 +101,73 @@ int upload_bases(const uint64_t* bases, const uint8_t* infinity, size_t n, Bases
     return GH_OK;
 }
 
+// Precomputed shift table for a resident key (msm_kernels.h section 0): rows w = 0 .. W-1 of
+// 2^(c w) P_i.  c == 0 picks the window from n.  The table costs W x the bases' footprint
+// (n = 2^20 G1, c = 21: 36 x 218 MB = 7.8 GB of the 288 GB), built once per key in slabs.
+inline int precompute_window(size_t n, int deg) {
+    int lg = 0;
+    while (((size_t)1 << (lg + 1)) <= n) lg++;
+    if (g.window_override > 0) return g.window_override;
+    // Measured on MI355X (profiles/r01_precompute_sweep.txt).  Only window sizes whose top window
+    // is well filled are used: 752 mod c = 14 (c = 18), 12 (20), 17 (21), 16 (23).  With 752 mod c = 4
+    // (c = 17, 22) the top window's n digits land on 16 counters and the bucket sort's atomics
+    // serialise (sort time x 2.5); c = 16 divides 752 and would add a carry-only window.
+    int c;
+    if (deg > 1) c = lg <= 19 ? 18 : 21;
+    else if (lg <= 17) c = 18;
+    else if (lg == 18) c = 20;
+    else if (lg <= 22) c = 21;
+    else c = 23;
+    return c;
+}
+
+template <class C>
+int precompute_bases(BasesBase* h, int c_req) {
+    typedef typename C::FC::T FT;
+    if (h->d_table) { HIPCHK(hipFree(h->d_table)); h->d_table = nullptr; h->pre_c = h->pre_W = 0; }
+    const size_t n = h->n;
+    if (n == 0) return GH_OK;
+    const int c = c_req > 0 ? c_req : precompute_window(n, C::F::DEG);
+    if (c < 2 || c > 24) { g_err = "precompute window must be in [2, 24]"; return GH_E_BAD_ARG; }
+    const int W = 752 / c + 1;
+    if ((size_t)W * n >= ((size_t)1 << 31)) { g_err = "precomputed table too large for 31-bit entries"; return GH_E_UNSUPPORTED; }
+    size_t free_b = 0, total_b = 0;
+    HIPCHK(hipMemGetInfo(&free_b, &total_b));
+    const size_t slab = n < ((size_t)1 << 20) ? n : ((size_t)1 << 20);
+    const size_t need = (size_t)W * n * sizeof(Aff<C>) + 2 * (size_t)(W - 1) * slab * sizeof(FT) + ((size_t)1 << 30);
+    if (need > free_b) { g_err = "not enough device memory for the precomputed table"; return GH_E_NOMEM; }
+    Aff<C>* table = nullptr;
+    FT *zs = nullptr, *zp = nullptr;
+    uint32_t* bad = nullptr;
+    int rc;
+    HIPCHK(hipMalloc((void**)&table, (size_t)W * n * sizeof(Aff<C>)));
+    if ((rc = pool_get("pre_zs", (size_t)(W - 1) * slab * sizeof(FT) + 8, (void**)&zs)) ||
+        (rc = pool_get("pre_zp", (size_t)(W - 1) * slab * sizeof(FT) + 8, (void**)&zp)) ||
+        (rc = pool_get("pre_bad", 16, (void**)&bad))) { hipFree(table); return rc; }
+    hipStream_t st = g.stream;
+    hipError_t e = hipMemcpyAsync(table, h->d_points, n * sizeof(Aff<C>), hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess) e = hipMemsetAsync(bad, 0, 4, st);
+    for (size_t i0 = 0; i0 < n && e == hipSuccess; i0 += slab) {
+        const size_t cnt = n - i0 < slab ? n - i0 : slab;
+        hipLaunchKernelGGL((msm_precompute_kernel<C>), dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, st,
+                           table, (const uint8_t*)h->d_inf, n, i0, cnt, slab, c, W, zs, zp, bad);
+        e = hipGetLastError();
+    }
+    uint32_t hbad = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&hbad, bad, 4, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { hipFree(table); g_err = std::string("precompute failed: ") + hipGetErrorString(e); return GH_E_HIP; }
+    if (hbad) {   // a base of 2-power order: 2^(c w) P hits infinity, which an affine table cannot hold
+        hipFree(table);
+        g_err = "precompute: a base has 2-power order; the key stays on the per-window path";
+        return GH_E_UNSUPPORTED;
+    }
+    h->d_table = table;
+    h->pre_c = c;
+    h->pre_W = W;
+    return GH_OK;
+}
+
 // Horner over windows, high to low (variable_base.rs:73-82).  Per window the device delivers
 // (T, PW, PS, PA, PB) with  R_w = PW 2^(u+6) + PS 2^u + PA 2^6 + PB  and T = plain sum of the
 // window's buckets; the terms of acc * 2^c + R_w are folded by descending exponent so that the
@@ -171,6 +238,41 @@ void fold_windows(const std::vector<Proj<C>>& hw, int W, int c, int u, int top_u
     }
 }
 
+// Merged windows (precomputed shift table): ONE bucket set of nb slots, cut into Wp pseudo-windows
+// of Q = 2^q slots for the two-level wave reduction; slot s = w' Q + k, so
+//   sum_s s B_s = sum_w' R_w' + Q sum_w' w' T_w'
+// with R_w' = PW 2^(u+6) + PS 2^u + PA 2^6 + PB as above and T_w' the plain sum of pseudo-window w'.
+template <class HC>
+Proj<HC> fold_merged_generic(const std::vector<Proj<HC>>& hw, int Wp, int q, int u) {
+    auto PT = [&](int which, int w, int k) -> const Proj<HC>& { return hw[(size_t)(which * Wp + w) * 3 + k]; };
+    Proj<HC> spw = proj_zero<HC>(), sps = proj_zero<HC>(), spa = proj_zero<HC>(), spb = proj_zero<HC>();
+    Proj<HC> run = proj_zero<HC>(), st = proj_zero<HC>();
+    for (int w = Wp - 1; w >= 0; w--) {
+        spw = proj_add<HC>(spw, PT(0, w, 1));
+        sps = proj_add<HC>(sps, PT(0, w, 2));
+        spa = proj_add<HC>(spa, PT(1, w, 0));
+        spb = proj_add<HC>(spb, PT(2, w, 0));
+        if (w >= 1) { run = proj_add<HC>(run, PT(0, w, 0)); st = proj_add<HC>(st, run); }   // sum_w' w' T_w'
+    }
+    FoldTerm<HC> t[5] = {{u + 6, &spw}, {u, &sps}, {6, &spa}, {0, &spb}, {q, &st}};
+    Proj<HC> acc = fold_terms<HC>(t, 5);
+    if (proj_is_zero<HC>(acc)) acc = proj_zero<HC>();
+    return acc;
+}
+template <class C>
+void fold_merged(const std::vector<Proj<C>>& hw, int Wp, int q, int u, uint64_t* out_xyz) {
+    typedef typename HostCurveOf<C>::type HC;
+    if constexpr (HostCurveOf<C>::fast) {
+        std::vector<Proj<HC>> h64(hw.size());
+        for (size_t i = 0; i < hw.size(); i++) proj_to_abi_host<C>(reinterpret_cast<uint64_t*>(&h64[i]), hw[i]);
+        Proj<HC> acc = fold_merged_generic<HC>(h64, Wp, q, u);
+        memcpy(out_xyz, &acc, sizeof(acc));
+    } else {
+        Proj<C> acc = fold_merged_generic<C>(hw, Wp, q, u);
+        proj_to_abi_host<C>(out_xyz, acc);
+    }
+}
+
 template <class C>
 int msm_run(BasesBase* h, const void* d_scalars, size_t n_scalars, uint64_t* out_xyz) {
     size_t n = h->n < n_scalars ? h->n : n_scalars;
@@ -181,17 +283,25 @@ int msm_run(BasesBase* h, const void* d_scalars, size_t n_scalars, uint64_t* out
         g.last_msm = tm;
         return GH_OK;
     }
-    const int c = auto_window(n, C::F::DEG);
+    // merged: the key carries a precomputed shift table -> all windows share one bucket set
+    const bool merged = h->d_table != nullptr && (g.window_override == 0 || g.window_override == h->pre_c);
+    const int c = merged ? h->pre_c : auto_window(n, C::F::DEG);
     // after sign folding the scalar magnitudes are below 2^752 (msm_kernels.h, digits kernel)
     const int W = 752 / c + 1;
-    const int top_unsigned = (752 % c == 0 && W >= 2) ? 1 : 0;
+    const int top_unsigned = (!merged && 752 % c == 0 && W >= 2) ? 1 : 0;
     const uint32_t nb = (1u << (c - 1)) + 1;
-    const size_t total = (size_t)W * nb;
+    // bucket sets the reduction sees: W windows of nb slots, or (merged) Wp pseudo-windows of Q slots
+    const int q = 15;
+    const uint32_t Q = merged ? (nb <= (1u << q) + 1 ? nb : (1u << q)) : nb;
+    const int RW = merged ? (int)((nb + Q - 1) / Q) : W;
+    const size_t total = merged ? (size_t)nb : (size_t)W * nb;          // buckets that exist
+    const size_t slots = (size_t)RW * Q;                                // bucket array incl. padding
+    const uint32_t win_stride = merged ? 0u : nb;
     static const int env_L1 = getenv("GH_REDUCE_L") ? atoi(getenv("GH_REDUCE_L")) : 0;
     int L1 = MSM_REDUCE_L;                                         // items per lane, level 1 (power of two)
     if (env_L1 == 4 || env_L1 == 8 || env_L1 == 16 || env_L1 == 32) L1 = env_L1;
     const uint32_t seg_slots = 64 * (uint32_t)L1;
-    const uint32_t segs_per_window = (nb + seg_slots - 1) / seg_slots;
+    const uint32_t segs_per_window = (Q + seg_slots - 1) / seg_slots;
     const int L2 = (int)((segs_per_window + 63) / 64);             // items per lane, level 2 (one wave per window)
     if ((size_t)W * n >= ((size_t)1 << 32) || total >= ((size_t)1 << 31)) {
         g_err = "MSM too large for 32-bit bucket offsets";
@@ -208,7 +318,8 @@ int msm_run(BasesBase* h, const void* d_scalars, size_t n_scalars, uint64_t* out
     // Heavy threshold.  Buckets are walked longest first, one per thread at ~78 us per addition
     // (2 waves / SIMD), so a bucket of s entries is free as long as s * 78 us stays well inside the
     // kernel's own duration (~ W n / 1.65e9 s); beyond that it would be the tail, and is split.
-    uint32_t heavy_thr = (uint32_t)((4 * n) >> (c - 1));
+    // (merged windows: at least twice the mean bucket W n / 2^(c-1), so that chunking stays the exception)
+    uint32_t heavy_thr = merged ? (uint32_t)((2 * (size_t)W * n) >> (c - 1)) : (uint32_t)((4 * n) >> (c - 1));
     {
         const uint32_t by_duration = (uint32_t)((double)W * (double)n * 3.1e-6);
         if (heavy_thr < by_duration) heavy_thr = by_duration;
@@ -232,9 +343,9 @@ int msm_run(BasesBase* h, const void* d_scalars, size_t n_scalars, uint64_t* out
     POOL("size_cursor", size_cursor, MSM_SIZE_BINS * 4)
     POOL("chunk_start", chunk_start, (max_heavy + 2) * 4)
     POOL("plan", plan, 16)
-    POOL("buckets", buckets, total * sizeof(Proj<C>))
-    POOL("seg_out", seg_out, (size_t)W * segs_per_window * 3 * sizeof(Proj<C>))
-    POOL("win_out", win_out, (size_t)3 * W * 3 * sizeof(Proj<C>))
+    POOL("buckets", buckets, slots * sizeof(Proj<C>))
+    POOL("seg_out", seg_out, (size_t)RW * segs_per_window * 3 * sizeof(Proj<C>))
+    POOL("win_out", win_out, (size_t)3 * RW * 3 * sizeof(Proj<C>))
 #undef POOL
     hipStream_t st = g.stream;
     static const bool dbg = getenv("GH_DEBUG") != nullptr;
@@ -249,7 +360,7 @@ int msm_run(BasesBase* h, const void* d_scalars, size_t n_scalars, uint64_t* out
     HIPCHK(hipMemsetAsync(counts, 0, total * 4, st));
     HIPCHK(hipMemsetAsync(size_hist, 0, MSM_SIZE_BINS * 4, st));
     hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
-                       (const uint32_t*)d_scalars, (const uint8_t*)h->d_inf, n, c, W, nb, top_unsigned, scalar_modulus<C>(), digits, counts);
+                       (const uint32_t*)d_scalars, (const uint8_t*)h->d_inf, n, c, W, win_stride, top_unsigned, scalar_modulus<C>(), digits, counts);
     HIPCHK(hipGetLastError());
     TRACE("digits done")
     if ((rc = device_scan(counts, starts, total, "scan_tmp"))) return rc;
@@ -261,7 +372,9 @@ int msm_run(BasesBase* h, const void* d_scalars, size_t n_scalars, uint64_t* out
     hipLaunchKernelGGL(msm_heavy_plan_kernel, dim3(1), dim3(1), 0, st, (const uint32_t*)size_hist, (const uint32_t*)counts,
                        (const uint32_t*)order, heavy_chunk, chunk_start, plan);
     hipLaunchKernelGGL(msm_scatter_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)W), dim3(256), 0, st,
-                       (const int32_t*)digits, n, W, nb, cursor, sorted);
+                       (const int32_t*)digits, n, W, win_stride, merged ? (uint32_t)h->n : 0u, cursor, sorted);
+    if (slots > total)   // padding slots of the last pseudo-window: infinity (Z = 0)
+        HIPCHK(hipMemsetAsync((void*)(buckets + total), 0, (slots - total) * sizeof(Proj<C>), st));
     HIPCHK(hipGetLastError());
     TRACE("scatter done")
     uint32_t hplan[2] = {0, 0};
@@ -275,6 +388,7 @@ int msm_run(BasesBase* h, const void* d_scalars, size_t n_scalars, uint64_t* out
     if (n_heavy > 0 && (rc = pool_get("partials", (size_t)n_chunks * sizeof(Proj<C>), (void**)&partials))) return rc;
     // 2 waves / SIMD (256 VGPRs, 184 B scratch) measured 29.3 ms vs 34.6 ms for 1 wave (297 registers) at 2^20
     static const int acc_waves = getenv("GH_ACC_WAVES") ? atoi(getenv("GH_ACC_WAVES")) : 2;
+    const void* src_points = merged ? h->d_table : h->d_points;
     HIPCHK(hipEventRecord(g.ev[2], st));
     {
         // one launch: the chunks of the heavy buckets first, then every other bucket, longest first
@@ -290,7 +404,7 @@ int msm_run(BasesBase* h, const void* d_scalars, size_t n_scalars, uint64_t* out
                 constexpr int LANES = FS::LANES;
                 const size_t waves = (tasks + (64 / LANES) - 1) / (64 / LANES);
                 hipLaunchKernelGGL((msm_accumulate_split_kernel<C, FS, LANES>), dim3((unsigned)((waves * 64 + 255) / 256)), dim3(256), 0, st,
-                                   (const Aff<C>*)h->d_points, (const uint32_t*)sorted, (const uint32_t*)starts,
+                                   (const Aff<C>*)src_points, (const uint32_t*)sorted, (const uint32_t*)starts,
                                    (const uint32_t*)counts, (const uint32_t*)order, (uint32_t)total, (const Aff<C>*)salts, buckets,
                                    (const uint32_t*)chunk_start, n_heavy, n_chunks, heavy_chunk, partials);
             }
@@ -298,12 +412,12 @@ int msm_run(BasesBase* h, const void* d_scalars, size_t n_scalars, uint64_t* out
         if (!(is_g2 && !no_split)) {
         if (acc_waves >= 2)
             hipLaunchKernelGGL((msm_accumulate_kernel<C, 2>), dim3((unsigned)((tasks + 255) / 256)), dim3(256), 0, st,
-                               (const Aff<C>*)h->d_points, (const uint32_t*)sorted, (const uint32_t*)starts,
+                               (const Aff<C>*)src_points, (const uint32_t*)sorted, (const uint32_t*)starts,
                                (const uint32_t*)counts, (const uint32_t*)order, (uint32_t)total, (const Aff<C>*)salts, buckets,
                                (const uint32_t*)chunk_start, n_heavy, n_chunks, heavy_chunk, partials);
         else
             hipLaunchKernelGGL((msm_accumulate_kernel<C, 1>), dim3((unsigned)((tasks + 255) / 256)), dim3(256), 0, st,
-                               (const Aff<C>*)h->d_points, (const uint32_t*)sorted, (const uint32_t*)starts,
+                               (const Aff<C>*)src_points, (const uint32_t*)sorted, (const uint32_t*)starts,
                                (const uint32_t*)counts, (const uint32_t*)order, (uint32_t)total, (const Aff<C>*)salts, buckets,
                                (const uint32_t*)chunk_start, n_heavy, n_chunks, heavy_chunk, partials);
         }
@@ -319,18 +433,18 @@ int msm_run(BasesBase* h, const void* d_scalars, size_t n_scalars, uint64_t* out
     HIPCHK(hipEventRecord(g.ev[4], st));
     TRACE("heavy done")
     {   // level 1: one wave per segment of 64 * L1 bucket slots -> (runW, A, Bv) per segment
-        WaveReduceIn<C> i0{buckets, 1, 0, nb, 0}, none{nullptr, 0, 0, 0, 0};
-        hipLaunchKernelGGL((msm_wave_reduce_kernel<C>), dim3((unsigned)(W * segs_per_window)), dim3(64), lds_wave, st,
-                           i0, none, none, (uint32_t)(W * segs_per_window), segs_per_window, L1, (const Aff<C>*)salts, seg_out);
+        WaveReduceIn<C> i0{buckets, 1, 0, Q, 0}, none{nullptr, 0, 0, 0, 0};
+        hipLaunchKernelGGL((msm_wave_reduce_kernel<C>), dim3((unsigned)(RW * segs_per_window)), dim3(64), lds_wave, st,
+                           i0, none, none, (uint32_t)(RW * segs_per_window), segs_per_window, L1, (const Aff<C>*)salts, seg_out);
         // level 2: one wave per window and per array: weighted program on runW, plain sums of A and Bv
         WaveReduceIn<C> r0{seg_out, 3, 0, segs_per_window, 0}, r1{seg_out, 3, 1, segs_per_window, 1}, r2{seg_out, 3, 2, segs_per_window, 1};
-        hipLaunchKernelGGL((msm_wave_reduce_kernel<C>), dim3((unsigned)(3 * W)), dim3(64), lds_wave, st,
-                           r0, r1, r2, (uint32_t)W, 1u, L2, (const Aff<C>*)salts, win_out);
+        hipLaunchKernelGGL((msm_wave_reduce_kernel<C>), dim3((unsigned)(3 * RW)), dim3(64), lds_wave, st,
+                           r0, r1, r2, (uint32_t)RW, 1u, L2, (const Aff<C>*)salts, win_out);
     }
     HIPCHK(hipGetLastError());
     TRACE("reduce done")
     HIPCHK(hipEventRecord(g.ev[5], st));
-    std::vector<Proj<C>> hw((size_t)9 * W);
+    std::vector<Proj<C>> hw((size_t)9 * RW);
     HIPCHK(hipMemcpyAsync(hw.data(), win_out, hw.size() * sizeof(Proj<C>), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     auto t_fold0 = std::chrono::steady_clock::now();
@@ -341,7 +455,13 @@ int msm_run(BasesBase* h, const void* d_scalars, size_t n_scalars, uint64_t* out
     //   acc*2^c + R_w = (((acc*2^(c-u-6) + PW)*2^6 + PS)*2^(u-6) + PA)*2^6 + PB        (c >= u + 6)
     int u = 6;
     while ((1 << (u - 6)) < L1) u++;
-    fold_windows<C>(hw, W, c, u, top_unsigned, out_xyz);
+    if (merged) {
+        int lq = 0;
+        while ((1u << lq) < Q) lq++;            // RW > 1 only with Q = 2^q; for RW == 1 the term is empty
+        fold_merged<C>(hw, RW, lq, u, out_xyz);
+    } else {
+        fold_windows<C>(hw, W, c, u, top_unsigned, out_xyz);
+    }
     TRACE("fold done")
 #undef TRACE
     auto t_end = std::chrono::steady_clock::now();
@@ -412,7 +532,8 @@ template <class C> int to_affine_host(const uint64_t* xyz, uint64_t* out_xy, uin
     namespace gh_rt {                                                                          \
     const MsmOps* NAME() {                                                                     \
         static const MsmOps ops = {&upload_bases<CURVE>, &msm_run<CURVE>, &msm_host<CURVE>,    \
-                                   &proj_add_host<CURVE>, &to_affine_host<CURVE>};             \
+                                   &proj_add_host<CURVE>, &to_affine_host<CURVE>,              \
+                                   &precompute_bases<CURVE>};                                  \
         return &ops;                                                                           \
     }                                                                                          \
     }

@@ -92,6 +92,121 @@ __global__ void __launch_bounds__(256) msm_convert_bases_kernel(const uint32_t* 
     for (int w = 0; w < (int)(sizeof(Aff<C>) / 8); w++) q[w] = s[w];
 }
 
+// ---------------------------------------------------------------- 0. precomputed shift tables
+// Bases are static per proving key (groth16/mod.rs:158-170), and 288 GB of HBM hold a lot of them:
+// for a resident key the library can store, next to P_i, the points 2^(c w) P_i for every window w
+// (table row w; W rows of n affine points).  Window w of scalar i then adds table[w][i] instead of
+// P_i, all windows share ONE set of 2^(c-1) buckets, and the per-window reduction and the Horner
+// fold over windows (variable_base.rs:60-82) collapse into a single bucket reduction.  With the
+// bucket count decoupled from the window count, c can grow (c = 21 at n = 2^20: 36 additions per
+// pair instead of 48).
+//
+// One thread per base: c doublings per row (out-of-line dbl-2007-bl), projective rows parked in the
+// table / a scratch array, then ONE field inversion per base (Montgomery's trick over its W - 1 Z
+// coordinates, as batch_normalization does: short_weierstrass_projective.rs:402-442) turns them
+// into affine rows.
+template <class P> __device__ __attribute__((noinline)) Fp dev_fp_inv(const Fp& a) {   // a^(p-2)
+    uint32_t e[NL];
+    int32_t bw = -2;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        int32_t x = (int32_t)P::P[i] + bw;
+        e[i] = (uint32_t)x & LM;
+        bw = x >> 31;
+    }
+    Fp r = fp_one<P>();
+#pragma unroll
+    for (int i = NL - 1; i >= 0; i--) {
+        const uint32_t ei = e[i];
+#pragma nounroll
+        for (int b = LB - 1; b >= 0; b--) {
+            r = fp_sqr_call<P>(r);
+            if ((ei >> b) & 1u) r = fp_mul_call<P>(r, a);
+        }
+    }
+    return r;
+}
+template <class F> struct DevInv;
+template <class P, bool I> struct DevInv<F1<P, I>> {
+    static __device__ __forceinline__ Fp inv(const Fp& a) { return dev_fp_inv<P>(a); }
+};
+template <class P, int NR, bool I> struct DevInv<F2<P, NR, I>> {   // (a0 - a1 X) / (a0^2 - NR a1^2)   (fp2.rs inverse)
+    static __device__ __forceinline__ Fp2T inv(const Fp2T& a) {
+        Fp n = fp_sub<P>(fp_sqr_call<P>(a.c0), fp_mul_small<P, NR>(fp_sqr_call<P>(a.c1)));
+        Fp ni = dev_fp_inv<P>(n);
+        return Fp2T{fp_mul_call<P>(a.c0, ni), fp_neg<P>(fp_mul_call<P>(a.c1, ni))};
+    }
+};
+template <class P, int NR, bool I> struct DevInv<F3<P, NR, I>> {   // norm-based inverse (fp3.rs inverse)
+    static __device__ __forceinline__ Fp3T inv(const Fp3T& a) {
+        Fp t0 = fp_sqr_call<P>(a.c0), t1 = fp_sqr_call<P>(a.c1), t2 = fp_sqr_call<P>(a.c2);
+        Fp t3 = fp_mul_call<P>(a.c0, a.c1), t4 = fp_mul_call<P>(a.c0, a.c2), t5 = fp_mul_call<P>(a.c1, a.c2);
+        Fp c0 = fp_sub<P>(t0, fp_mul_small<P, NR>(t5));
+        Fp c1 = fp_sub<P>(fp_mul_small<P, NR>(t2), t3);
+        Fp c2 = fp_sub<P>(t1, t4);
+        Fp n = fp_add<P>(fp_mul_call<P>(a.c0, c0),
+                         fp_mul_small<P, NR>(fp_add<P>(fp_mul_call<P>(a.c2, c1), fp_mul_call<P>(a.c1, c2))));
+        Fp ni = dev_fp_inv<P>(n);
+        return Fp3T{fp_mul_call<P>(c0, ni), fp_mul_call<P>(c1, ni), fp_mul_call<P>(c2, ni)};
+    }
+};
+
+template <class T> __device__ __forceinline__ T ld_words(const T* p) {
+    T r;
+    const uint2* q = reinterpret_cast<const uint2*>(p);
+    uint2* d = reinterpret_cast<uint2*>(&r);
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(T) / 8); i++) d[i] = q[i];
+    return r;
+}
+template <class T> __device__ __forceinline__ void st_words(T* p, const T& v) {
+    uint2* q = reinterpret_cast<uint2*>(p);
+    const uint2* s = reinterpret_cast<const uint2*>(&v);
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(T) / 8); i++) q[i] = s[i];
+}
+
+// table: W rows of n points (row 0 = the bases themselves, already written by the caller);
+// this launch covers bases [i0, i0 + cnt).  zs / zp: (W - 1) x slab field elements of scratch
+// (Z_w and the running products Z_1 .. Z_w).  bad[0] is set when a doubling chain reaches infinity
+// (a base of 2-power order: the caller then keeps the plain per-window path for this key).
+template <class C>
+__global__ void __launch_bounds__(64)
+msm_precompute_kernel(Aff<C>* __restrict__ table, const uint8_t* __restrict__ infinity, size_t n, size_t i0, size_t cnt,
+                      size_t slab, int c, int W, typename C::FC::T* __restrict__ zs, typename C::FC::T* __restrict__ zp,
+                      uint32_t* __restrict__ bad) {
+    typedef typename C::FC F;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= cnt) return;
+    const size_t i = i0 + t;
+    if (infinity != nullptr && infinity[i] != 0) {   // never read (its digits are dropped); keep the rows defined
+        const Aff<C> b = ld_words(table + i);
+        for (int w = 1; w < W; w++) st_words(table + (size_t)w * n + i, b);
+        return;
+    }
+    const Aff<C> b = ld_words(table + i);
+    Proj<C> p{b.x, b.y, F::one()};
+    typename F::T run = F::one();
+    for (int w = 1; w < W; w++) {
+        for (int d = 0; d < c; d++) p = proj_dbl_call<C>(p);
+        if (F::is_zero(p.z)) { atomicOr(bad, 1u); return; }
+        st_words(table + (size_t)w * n + i, Aff<C>{p.x, p.y});
+        st_words(zs + (size_t)(w - 1) * slab + t, p.z);
+        run = F::mul(run, p.z);
+        st_words(zp + (size_t)(w - 1) * slab + t, run);
+    }
+    typename F::T inv = DevInv<F>::inv(run);   // 1 / (Z_1 ... Z_(W-1))
+    for (int w = W - 1; w >= 1; w--) {
+        typename F::T zi = inv;
+        if (w > 1) zi = F::mul(inv, ld_words(zp + (size_t)(w - 2) * slab + t));   // 1 / Z_w
+        inv = F::mul(inv, ld_words(zs + (size_t)(w - 1) * slab + t));
+        Aff<C> q = ld_words(table + (size_t)w * n + i);
+        q.x = F::mul(q.x, zi);
+        q.y = F::mul(q.y, zi);
+        st_words(table + (size_t)w * n + i, q);
+    }
+}
+
 // Wave-aggregated counter increment: returns the old value of base[key] as if every active lane
 // had done atomicAdd(base + key, 1).  Up to `iters` distinct keys are combined into one atomic
 // each (leader election by ballot); the rest fall back to per-lane atomics.  Random digits pay a
@@ -119,7 +234,9 @@ static __device__ __forceinline__ uint32_t wave_agg_inc(uint32_t* base, uint32_t
 
 // ---------------------------------------------------------------- 1. digits + histogram
 // scalars: n x 24 words canonical (< r).  digits[w * n + i] = signed digit (0 = no contribution).
-// counts[w * nb + |d|] += 1, nb = 2^(c-1) + 1 (slot 0 unused).
+// counts[w * win_stride + |d|] += 1; win_stride = nb = 2^(c-1) + 1 (slot 0 unused) gives every
+// window its own bucket set; win_stride = 0 files all windows into ONE bucket set (precomputed
+// shift tables, section 0 below: window w then reads its bases from table row w).
 //
 // (a) sign folding: s > r/2 is replaced by r - s with the base negated (s P = (r - s)(-P)), so the
 //     magnitude is below 2^752 and bit 752 never needs a window.
@@ -136,7 +253,7 @@ struct MsmModulus { uint32_t w[24]; };
 
 static __global__ void __launch_bounds__(256)
 msm_digits_kernel(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ infinity, size_t n, int c,
-                  int num_windows, uint32_t nb, int top_unsigned, MsmModulus r,
+                  int num_windows, uint32_t win_stride, int top_unsigned, MsmModulus r,
                   int32_t* __restrict__ digits, uint32_t* __restrict__ counts) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = i < n;
@@ -188,7 +305,7 @@ msm_digits_kernel(const uint32_t* __restrict__ scalars, const uint8_t* __restric
         if (skip) d = 0;
         if (valid) digits[(size_t)w * n + i] = d;
         const uint32_t mag = d < 0 ? (uint32_t)(-d) : (uint32_t)d;
-        wave_agg_inc(counts + (size_t)w * nb, mag, d != 0, 12);
+        wave_agg_inc(counts + (size_t)w * win_stride, mag, d != 0, 12);
     }
 }
 
@@ -241,14 +358,15 @@ static __global__ void msm_heavy_plan_kernel(const uint32_t* size_hist, const ui
 
 // ---------------------------------------------------------------- 3. scatter
 static __global__ void __launch_bounds__(256)
-msm_scatter_kernel(const int32_t* __restrict__ digits, size_t n, int num_windows, uint32_t nb,
+msm_scatter_kernel(const int32_t* __restrict__ digits, size_t n, int num_windows, uint32_t win_stride,
+                   uint32_t row_stride /* 0, or the table's row length (merged windows) */,
                    uint32_t* __restrict__ cursor /* = copy of starts */, uint32_t* __restrict__ sorted) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     int w = blockIdx.y;
     const int32_t d = i < n ? digits[(size_t)w * n + i] : 0;
     const uint32_t mag = d < 0 ? (uint32_t)(-d) : (uint32_t)d;
-    const uint32_t pos = wave_agg_inc(cursor + (size_t)w * nb, mag, d != 0, 12);
-    if (d != 0) sorted[pos] = (uint32_t)i | (d < 0 ? 0x80000000u : 0u);
+    const uint32_t pos = wave_agg_inc(cursor + (size_t)w * win_stride, mag, d != 0, 12);
+    if (d != 0) sorted[pos] = ((uint32_t)i + (uint32_t)w * row_stride) | (d < 0 ? 0x80000000u : 0u);
 }
 
 // ---------------------------------------------------------------- 4. bucket accumulation

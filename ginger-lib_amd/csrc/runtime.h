@@ -63,6 +63,8 @@ struct BasesBase {
     size_t n = 0;
     void* d_points = nullptr;   // n x Aff<C>, internal layout
     uint8_t* d_inf = nullptr;   // n bytes or null
+    void* d_table = nullptr;    // precomputed shift table: pre_W rows of n x Aff<C> (row w = 2^(pre_c w) P), or null
+    int pre_c = 0, pre_W = 0;
     uint32_t magic = 0x6768424au;
 };
 struct MsmOps {
@@ -72,6 +74,7 @@ struct MsmOps {
                 size_t n_scalars, uint64_t* out_xyz);
     int (*proj_add)(uint64_t* acc_xyz, const uint64_t* p_xyz);
     int (*to_affine)(const uint64_t* xyz, uint64_t* out_xy, uint8_t* is_infinity);
+    int (*precompute)(BasesBase* h, int window_bits);
 };
 const MsmOps* msm_ops_mnt4753_g1();
 const MsmOps* msm_ops_mnt4753_g2();

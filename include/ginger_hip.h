@@ -93,6 +93,15 @@ int gh_bases_upload(gh_curve_t curve, const uint64_t* bases, const uint8_t* infi
                     gh_bases_t* out_handle);
 int gh_bases_free(gh_bases_t handle);
 size_t gh_bases_len(gh_bases_t handle);
+/* Optional, once per resident key: build the shift table 2^(c w) P_i, w = 0 .. floor(752/c), in
+ * device memory (W x the footprint of the bases; GH_E_NOMEM if it does not fit, and the handle
+ * stays usable without it).  Later gh_msm_resident* calls on the handle then file all windows into
+ * ONE bucket set: fewer additions per pair (c = 21 at 2^20 pairs: 36 instead of 48), one bucket
+ * reduction, no window fold.  Results are the same group element as without the table (the affine
+ * image is what variable_base.rs:85-90 + into_affine() define).  window_bits 0 = choose from n.
+ * GH_E_UNSUPPORTED if a base has 2-power order (2^(c w) P = infinity has no affine form).   */
+int gh_bases_precompute(gh_bases_t handle, int window_bits);
+int gh_bases_precomputed_window(gh_bases_t handle); /* c of the table, 0 if none */
 /* scalars on the host */
 int gh_msm_resident(gh_bases_t handle, const uint64_t* scalars, size_t n_scalars, uint64_t* out_xyz);
 /* scalars already in device memory (from gh_dev_alloc); used by the benchmark's HBM-resident timing

@@ -275,3 +275,76 @@ def test_msm_full_size_properties(gpu):
     exp = S.oracle_msm(curve, bases[:k], None, s[:k], 16)
     assert affine_eq(gpu, curve, rb.msm(s[:k]), exp)
     rb.free()
+
+
+# ------------------------------------------------------------------------------ MSM on a precomputed shift table
+@pytest.mark.parametrize("curve,n,windows", [("mnt4753_g1", 300, (0, 4, 7, 13, 16, 17, 19)), ("mnt6753_g1", 200, (0, 11, 18)),
+                                             ("mnt4753_g2", 90, (0, 9, 17)), ("mnt6753_g2", 60, (0, 12))])
+def test_msm_precomputed_vs_oracle(gpu, curve, n, windows):
+    """gh_bases_precompute: every window files into one bucket set (table row w = 2^(c w) P).  Same
+    affine result as the oracle for: c | 752 (carry-only top window), one and several pseudo-windows
+    of the reduction (c <= 16 / c >= 17), shorter scalar vectors, infinity / duplicate / opposite bases,
+    scalars 0, 1, r - 1, around r/2."""
+    C = pyref.CURVES[curve]
+    r = C.order
+    rng = pyref.Rng(4242 + n)
+    pool = S.chain_points(C, min(n, 64), rng)
+    pts = [pool[i % len(pool)] for i in range(n)]
+    scal = [rng.field_elem(r) for _ in range(n)]
+    scal[:10] = [0, 1, 2, r - 1, r - 2, (r - 1) // 2, (r + 1) // 2, (r + 3) // 2, 1 << 751, (1 << 752) + 12345]
+    pts[12] = None
+    pts[14] = pts[13]; scal[14] = scal[13]
+    pts[16] = C.neg(pts[15]); scal[16] = scal[15]
+    b, inf = S.bases_array(C, pts)
+    s = S.scalar_array(scal)
+    exp = S.oracle_msm(curve, b, inf, s, 16)
+    exp_short = S.oracle_msm(curve, b, inf, s[:n // 3], 16)
+    rb = gpu.ResidentBases(curve, b, inf)
+    plain = rb.msm(s)
+    assert affine_eq(gpu, curve, plain, exp)
+    for c in windows:
+        used = rb.precompute(c)
+        assert used == (c if c else used) and used >= 2
+        got = rb.msm(s)
+        tm = gpu.msm_last_timing()
+        assert tm["window_bits"] == used and tm["num_windows"] == 752 // used + 1
+        assert affine_eq(gpu, curve, got, exp), (curve, c)
+        assert affine_eq(gpu, curve, rb.msm(s[:n // 3]), exp_short), (curve, c, "short")
+    rb.free()
+
+
+def test_msm_precomputed_skewed_and_large(gpu):
+    """witness-like scalars (long buckets -> chunk path) on the merged bucket set, and a 2^16-pair run
+    against the oracle (BASELINE config 1 size) with the automatic table window"""
+    curve = "mnt4753_g1"
+    C = pyref.CURVES[curve]
+    rng = pyref.Rng(6)
+    pool = S.chain_points(C, 256, rng)
+    n = 6000
+    pts = [pool[(i * 7) % 256] for i in range(n)]
+    big = rng.field_elem(C.order)
+    scal = []
+    for i in range(n):
+        m = i % 10
+        scal.append(1 if m < 5 else 0 if m == 5 else 2 if m == 6 else big if m == 7 else (i * 12345) % 65536 if m == 8 else rng.field_elem(C.order))
+    b, inf = S.bases_array(C, pts)
+    s = S.scalar_array(scal)
+    rb = gpu.ResidentBases(curve, b, inf)
+    rb.precompute(0)
+    assert affine_eq(gpu, curve, rb.msm(s), S.oracle_msm(curve, b, inf, s, 16))
+    rb.free()
+    n = 1 << 16
+    pb, _ = S.bases_array(C, pool)
+    bases = np.tile(pb, (n // 256, 1))
+    s = S.random_scalars_np(n, seed=21, below=C.order)
+    rb = gpu.ResidentBases(curve, bases)
+    c = rb.precompute(0)
+    got = rb.msm(s)
+    assert gpu.msm_last_timing()["window_bits"] == c
+    assert affine_eq(gpu, curve, got, S.oracle_msm(curve, bases, None, s, 16))
+    # the override of the window size switches a table-carrying key back to the per-window path
+    gpu.msm_set_window(13)
+    assert affine_eq(gpu, curve, rb.msm(s), S.oracle_msm(curve, bases, None, s, 16))
+    assert gpu.msm_last_timing()["num_windows"] == 58
+    gpu.msm_set_window(0)
+    rb.free()
