@@ -298,7 +298,14 @@ int msm_run(BasesBase* h, const void* d_scalars, size_t n_scalars, uint64_t* out
     const size_t slots = (size_t)RW * Q;                                // bucket array incl. padding
     const uint32_t win_stride = merged ? 0u : nb;
     static const int env_L1 = getenv("GH_REDUCE_L") ? atoi(getenv("GH_REDUCE_L")) : 0;
-    int L1 = MSM_REDUCE_L;                                         // items per lane, level 1 (power of two)
+    // items per lane, level 1 (power of two).  The wave programs are latency chains (2 L1 + 17 steps,
+    // then 2 L2 + 17): as long as the launch stays within one wave per SIMD (1024 on MI355X) a shorter
+    // L1 only shortens the chain; beyond that the steps of co-resident waves add up again
+    // (measured at 2^20 buckets: L1 = 16 -> 6.2 ms, 8 -> 6.8, 4 -> 8.2, 32 -> 7.9).
+    int L1 = MSM_REDUCE_L;
+    // (Fq3 stays at 16: its out-of-line products make the steps scratch-bandwidth bound, and more,
+    //  shorter programs were measured slower: 62.8 ms vs 58.7 ms at 2^17 buckets)
+    while (C::F::DEG < 3 && L1 > 4 && (size_t)RW * ((Q + 32u * L1 - 1) / (32u * L1)) <= 1024) L1 >>= 1;
     if (env_L1 == 4 || env_L1 == 8 || env_L1 == 16 || env_L1 == 32) L1 = env_L1;
     const uint32_t seg_slots = 64 * (uint32_t)L1;
     const uint32_t segs_per_window = (Q + seg_slots - 1) / seg_slots;
@@ -394,10 +401,8 @@ int msm_run(BasesBase* h, const void* d_scalars, size_t n_scalars, uint64_t* out
         // one launch: the chunks of the heavy buckets first, then every other bucket, longest first
         const size_t tasks = (size_t)n_chunks + (total - n_heavy);
         static const bool no_split = getenv("GH_NO_SPLIT") != nullptr;
-        // Only Fq2 is instantiated: the Fq3 lane-triple instance (F3S) is correct by construction but hipcc
-        // needed more than half an hour to compile it (unified 512-register allocation), so MNT6 G2
-        // stays on the out-of-line path for now.
-        constexpr bool is_g2 = std::is_same<C, Mnt4G2>::value;
+        // G2: one coefficient per lane, 2 (Fq2) / 3 (Fq3) lanes per task (msm_kernels.h 4b)
+        constexpr bool is_g2 = std::is_same<C, Mnt4G2>::value || std::is_same<C, Mnt6G2>::value;
         if constexpr (is_g2) {
             if (!no_split) {   // Fq2 / Fq3: one coefficient per lane, 2 / 3 lanes per task (msm_kernels.h 4b)
                 typedef typename std::conditional<std::is_same<C, Mnt4G2>::value, F2S<P4, 13>, F3S<P6, 11>>::type FS;
@@ -433,13 +438,17 @@ int msm_run(BasesBase* h, const void* d_scalars, size_t n_scalars, uint64_t* out
     HIPCHK(hipEventRecord(g.ev[4], st));
     TRACE("heavy done")
     {   // level 1: one wave per segment of 64 * L1 bucket slots -> (runW, A, Bv) per segment
-        WaveReduceIn<C> i0{buckets, 1, 0, Q, 0}, none{nullptr, 0, 0, 0, 0};
-        hipLaunchKernelGGL((msm_wave_reduce_kernel<C>), dim3((unsigned)(RW * segs_per_window)), dim3(64), lds_wave, st,
-                           i0, none, none, (uint32_t)(RW * segs_per_window), segs_per_window, L1, (const Aff<C>*)salts, seg_out);
+        WaveReduceIn<C> i0{buckets, 1, 0, Q, 0, (uint32_t)total}, none{nullptr, 0, 0, 0, 0, 0};
+        static const int env_wpb = getenv("GH_REDUCE_WPB") ? atoi(getenv("GH_REDUCE_WPB")) : 1;
+        int wpb = env_wpb >= 1 && (size_t)env_wpb * lds_wave <= 65536 && env_wpb <= 4 ? env_wpb : 1;   // waves per block
+        const unsigned nb1 = (unsigned)(RW * segs_per_window), nb2 = (unsigned)(3 * RW);
+        hipLaunchKernelGGL((msm_wave_reduce_kernel<C>), dim3((nb1 + wpb - 1) / wpb), dim3(64 * wpb), lds_wave * wpb, st,
+                           i0, none, none, nb1, 1u, segs_per_window, L1, (const Aff<C>*)salts, seg_out);
         // level 2: one wave per window and per array: weighted program on runW, plain sums of A and Bv
-        WaveReduceIn<C> r0{seg_out, 3, 0, segs_per_window, 0}, r1{seg_out, 3, 1, segs_per_window, 1}, r2{seg_out, 3, 2, segs_per_window, 1};
-        hipLaunchKernelGGL((msm_wave_reduce_kernel<C>), dim3((unsigned)(3 * RW)), dim3(64), lds_wave, st,
-                           r0, r1, r2, (uint32_t)RW, 1u, L2, (const Aff<C>*)salts, win_out);
+        const uint32_t all = 0xFFFFFFFFu;
+        WaveReduceIn<C> r0{seg_out, 3, 0, segs_per_window, 0, all}, r1{seg_out, 3, 1, segs_per_window, 1, all}, r2{seg_out, 3, 2, segs_per_window, 1, all};
+        hipLaunchKernelGGL((msm_wave_reduce_kernel<C>), dim3((nb2 + wpb - 1) / wpb), dim3(64 * wpb), lds_wave * wpb, st,
+                           r0, r1, r2, (uint32_t)RW, 3u, 1u, L2, (const Aff<C>*)salts, win_out);
     }
     HIPCHK(hipGetLastError());
     TRACE("reduce done")

@@ -565,16 +565,29 @@ template <class P, int NR> struct F3S {
     static __device__ __forceinline__ T sub(const T& a, const T& b) { return fp_sub<P>(a, b); }
     static __device__ __forceinline__ T dbl(const T& a) { return fp_dbl<P>(a); }
     static __device__ __forceinline__ T neg(const T& a) { return fp_neg<P>(a); }
+    // The three products of a lane run in a ROLLED loop (one fp_mul body per call site): with them
+    // unrolled the kernel held 33 inlined products and hipcc needed more than half an hour for it.
+    //   iteration m:  lane j takes a_((j - m) mod 3) * b_m, times NR when m > j (the wrapped terms)
     static __device__ __forceinline__ T mul(const T& a, const T& b) {
-        const int j = comp();
-        const T an = rot(a, 1), ap = rot(a, 2), bn = rot(b, 1), bp = rot(b, 2);
-        const T t1 = fp_mul<P>(a, sel3(j, b, bp, bn));
-        const T t2 = fp_mul<P>(ap, sel3(j, bn, b, bp));
-        const T t3 = fp_mul<P>(an, sel3(j, bp, bn, b));
-        // j = 0: t1 + NR (t2 + t3);  j = 1: t1 + t2 + NR t3;  j = 2: t1 + t2 + t3
-        const T s23 = fp_add<P>(t2, t3);
-        const T x = sel3(j, fp_mul_small<P, NR>(s23), fp_add<P>(t2, fp_mul_small<P, NR>(t3)), s23);
-        return fp_add<P>(t1, x);
+        const int lane = threadIdx.x & 63, j = lane % 3, base = lane - j;
+        T acc = fp_zero();
+#pragma nounroll
+        for (int m = 0; m < 3; m++) {
+            const int ja = j - m < 0 ? j - m + 3 : j - m;
+            T x, y;
+#pragma unroll
+            for (int i = 0; i < NL; i++) {
+                x.l[i] = (uint32_t)__shfl((int)a.l[i], base + ja);
+                y.l[i] = (uint32_t)__shfl((int)b.l[i], base + m);
+            }
+            T t = fp_mul<P>(x, y);
+            const T tn = fp_mul_small<P, NR>(t);
+            const bool wrap = m > j;
+#pragma unroll
+            for (int i = 0; i < NL; i++) t.l[i] = wrap ? tn.l[i] : t.l[i];
+            acc = fp_add<P>(acc, t);
+        }
+        return acc;
     }
     static __device__ __forceinline__ T sqr(const T& a) { return mul(a, a); }
     static __device__ __forceinline__ T mul_sub_mul(const T& a, const T& b, const T& c, const T& d) { return sub(mul(a, b), mul(c, d)); }
@@ -748,6 +761,7 @@ msm_heavy_combine_kernel(const Proj<C>* __restrict__ partials, const uint32_t* _
 template <class C> struct WaveReduceIn {
     const Proj<C>* base;   // item (w, k) = base[(w * count + k) * stride + offset]
     uint32_t stride, offset, count, mode;
+    uint32_t valid;        // items with flat index w * count + k >= valid are padding (infinity)
 };
 
 // branch-free projective addition with selects for the infinity cases; same = (p == q as points)
@@ -780,18 +794,39 @@ template <class C> __device__ __forceinline__ Proj<C> proj_add_sel(const Proj<C>
     return o;
 }
 
+// A block may carry blockDim.x / 64 INDEPENDENT waves (each its own program and LDS region, so the
+// exchanges need wave-level ordering only, no s_barrier).  Measured at 2^20 buckets: 1, 2, 3 or 4
+// waves per block, with or without a block barrier per step, all take the same 5.2 ms for level 1
+// (104 us per step with every SIMD occupied, 55 us on an otherwise idle chip) -- the default is 1.
+#define GH_WAVE_SYNC()                                           \
+    do {                                                         \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   \
+        __builtin_amdgcn_wave_barrier();                         \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   \
+    } while (0)
 template <class C>
-__global__ void __launch_bounds__(64, 2)
+__global__ void __launch_bounds__(256, 2)
 msm_wave_reduce_kernel(WaveReduceIn<C> in0, WaveReduceIn<C> in1, WaveReduceIn<C> in2, uint32_t blocks_per_input,
-                       uint32_t segs_per_window, int L, const Aff<C>* __restrict__ salts, Proj<C>* __restrict__ out) {
+                       uint32_t n_inputs, uint32_t segs_per_window, int L, const Aff<C>* __restrict__ salts,
+                       Proj<C>* __restrict__ out) {
     typedef typename C::F F;
     extern __shared__ uint32_t lds_raw[];
-    Proj<C>* sh = reinterpret_cast<Proj<C>*>(lds_raw);
-    const int lane = threadIdx.x;
-    const uint32_t which = blockIdx.x / blocks_per_input, blk = blockIdx.x % blocks_per_input;
+    const int lane = threadIdx.x & 63;
+    Proj<C>* sh = reinterpret_cast<Proj<C>*>(lds_raw) + 64 * (threadIdx.x >> 6);
+    const uint32_t gb = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);   // one program per wave
+    if (gb >= n_inputs * blocks_per_input) return;
+    const uint32_t which = gb / blocks_per_input, blk = gb % blocks_per_input;
     const WaveReduceIn<C> in = which == 0 ? in0 : (which == 1 ? in1 : in2);
     const uint32_t w = blk / segs_per_window, seg = blk % segs_per_window;
     const uint32_t item0 = seg * 64u * (uint32_t)L;
+    if ((size_t)w * in.count + item0 >= (size_t)in.valid) {   // segment of padding slots only: all sums are infinity
+        if (lane == 0) {
+            Proj<C>* oz = out + ((size_t)which * blocks_per_input + blk) * 3;
+            const Proj<C> z = proj_zero<C>();
+            st_proj<C>(oz, z); st_proj<C>(oz + 1, z); st_proj<C>(oz + 2, z);
+        }
+        return;
+    }
     const int NS1 = in.mode == 1 ? L : 2 * L - 1;
     const int NST = in.mode == 1 ? L + 6 : NS1 + 18;
     Proj<C> run = proj_zero<C>(), wacc = proj_zero<C>(), tmp = proj_zero<C>();
@@ -815,7 +850,7 @@ msm_wave_reduce_kernel(WaveReduceIn<C> in0, WaveReduceIn<C> in1, WaveReduceIn<C>
         }
         const bool exch = kind >= 2;
         if (exch && det == 0) st_proj<C>(sh + lane, kind == 2 ? wacc : run);
-        if (exch) __syncthreads();
+        if (exch) GH_WAVE_SYNC();
         bool active;
         Proj<C> q = proj_zero<C>();
         if (kind == 0) {
@@ -830,7 +865,7 @@ msm_wave_reduce_kernel(WaveReduceIn<C> in0, WaveReduceIn<C> in1, WaveReduceIn<C>
             active = kind == 3 ? partner < 64 : lane < off;
             if (active) q = ld_proj<C>(sh + partner);
         }
-        if (exch) __syncthreads();
+        if (exch) GH_WAVE_SYNC();
         const bool to_wacc = kind == 1 || kind == 2;
         Proj<C> p = to_wacc ? wacc : run;
         if (det > 0) {
