@@ -30,8 +30,8 @@ FIELDS = {"mnt4753_fr": 0, "mnt6753_fr": 1}
 ABI_SYMBOLS = [
     "gh_init", "gh_shutdown", "gh_last_error", "gh_device_name",
     "gh_msm", "gh_bases_upload", "gh_bases_free", "gh_bases_len", "gh_bases_precompute", "gh_bases_precomputed_window",
-    "gh_msm_resident", "gh_msm_resident_dev",
-    "gh_msm_set_window", "gh_msm_get_window", "gh_msm_last_timing",
+    "gh_msm_resident", "gh_msm_resident_dev", "gh_msm_resident_dev_batch",
+    "gh_msm_set_window", "gh_msm_get_window", "gh_msm_last_timing", "gh_msm_batch_timing",
     "gh_domain_supported", "gh_fft", "gh_fft_dev", "gh_vec_mul_dev", "gh_vec_sub_dev", "gh_vec_scale_dev",
     "gh_vec_mul", "gh_vec_scale", "gh_fft_last_kernel_ms", "gh_witness_map", "gh_witness_map_dev",
     "gh_dev_alloc", "gh_dev_free", "gh_dev_upload", "gh_dev_download", "gh_dev_sync",
@@ -77,9 +77,11 @@ def load_library():
     lib.gh_bases_precomputed_window.argtypes = [vp]
     lib.gh_msm_resident.argtypes = [vp, vp, sz, vp]
     lib.gh_msm_resident_dev.argtypes = [vp, vp, sz, vp]
+    lib.gh_msm_resident_dev_batch.argtypes = [vp, vp, vp, ci, vp]
     lib.gh_msm_set_window.argtypes = [ci]
     lib.gh_msm_get_window.argtypes = [ci, sz]
     lib.gh_msm_last_timing.argtypes = [ctypes.POINTER(MsmTiming)]
+    lib.gh_msm_batch_timing.argtypes = [ci, ctypes.POINTER(MsmTiming)]
     lib.gh_domain_supported.argtypes = [ci, sz, ctypes.POINTER(u32)]
     lib.gh_fft.argtypes = [ci, vp, sz, vp, u32, u32]
     lib.gh_fft_dev.argtypes = [ci, vp, u32, u32]
@@ -199,6 +201,21 @@ class ResidentBases:
             self.handle = ctypes.c_void_p()
 
 
+def msm_batch_dev(jobs):
+    """jobs: list of (ResidentBases, DeviceBuffer of scalars, n_scalars) on one curve -> list of projective sums.
+    One gh_msm_resident_dev_batch call: the MSMs are pipelined over HIP streams."""
+    if not jobs:
+        return []
+    k = len(jobs)
+    deg = CURVE_DEG[jobs[0][0].curve]
+    handles = (ctypes.c_void_p * k)(*[j[0].handle for j in jobs])
+    scal = (ctypes.c_void_p * k)(*[j[1].ptr for j in jobs])
+    ns = (ctypes.c_size_t * k)(*[int(j[2]) for j in jobs])
+    out = np.zeros(k * 36 * deg, dtype=np.uint64)
+    _check(load_library().gh_msm_resident_dev_batch(handles, scal, ns, k, _ptr(out)))
+    return [out[i * 36 * deg:(i + 1) * 36 * deg].copy() for i in range(k)]
+
+
 class VariableBaseMSM:
     """Mirror of algebra::msm::VariableBaseMSM (variable_base.rs:7-90)."""
 
@@ -227,6 +244,12 @@ def msm_set_window(c):
 def msm_last_timing():
     t = MsmTiming()
     _check(load_library().gh_msm_last_timing(ctypes.byref(t)))
+    return {k: getattr(t, k) for k, _ in MsmTiming._fields_}
+
+
+def msm_batch_timing(index):
+    t = MsmTiming()
+    _check(load_library().gh_msm_batch_timing(int(index), ctypes.byref(t)))
     return {k: getattr(t, k) for k, _ in MsmTiming._fields_}
 
 

@@ -3,6 +3,7 @@
 // the transforms in ntt.hip.  Build: __graft_entry__.py build() (hipcc --offload-arch=gfx950).
 #include <stdlib.h>
 #include <string.h>
+#include <vector>
 #include "runtime.h"
 #include "scan_kernels.h"
 
@@ -34,7 +35,14 @@ int ensure_init() {
         return GH_E_NO_DEVICE;
     }
     HIPCHK(hipStreamCreate(&g.stream));
+    {
+        int least = 0, greatest = 0;   // numerically: least priority >= greatest priority
+        HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIPCHK(hipStreamCreateWithPriority(&g.stream_acc, hipStreamDefault, least));
+        HIPCHK(hipStreamCreateWithPriority(&g.stream_red, hipStreamDefault, greatest));
+    }
     for (auto& ev : g.ev) HIPCHK(hipEventCreate(&ev));
+    for (auto& sl : g.pev) for (auto& ev : sl) HIPCHK(hipEventCreate(&ev));
     g.ready = true;
     return GH_OK;
 }
@@ -133,6 +141,11 @@ int gh_shutdown(void) {
         g.domains[f].clear();
     }
     for (auto& ev : g.ev) hipEventDestroy(ev);
+    for (auto& sl : g.pev) for (auto& ev : sl) hipEventDestroy(ev);
+    hipStreamSynchronize(g.stream_acc);
+    hipStreamSynchronize(g.stream_red);
+    hipStreamDestroy(g.stream_acc);
+    hipStreamDestroy(g.stream_red);
     hipStreamDestroy(g.stream);
     g.ready = false;
     return GH_OK;
@@ -216,6 +229,30 @@ int gh_msm_resident_dev(gh_bases_t handle, const void* d_scalars, size_t n_scala
     return ops->run(h, d_scalars, n_scalars, out_xyz);
 }
 
+int gh_msm_resident_dev_batch(const gh_bases_t* handles, const void* const* d_scalars, const size_t* n_scalars, int count,
+                              uint64_t* out_xyz) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (count < 0 || (count > 0 && (!handles || !d_scalars || !n_scalars || !out_xyz))) { g_err = "null argument"; return GH_E_BAD_ARG; }
+    if (count == 0) return GH_OK;
+    std::vector<BasesBase*> hs((size_t)count);
+    for (int i = 0; i < count; i++) {
+        BasesBase* h = reinterpret_cast<BasesBase*>(handles[i]);
+        if (!h || h->magic != 0x6768424au) { g_err = "bad bases handle"; return GH_E_BAD_HANDLE; }
+        if (h->curve != reinterpret_cast<BasesBase*>(handles[0])->curve) { g_err = "a batch must stay on one curve"; return GH_E_BAD_ARG; }
+        if (n_scalars[i] && !d_scalars[i]) { g_err = "null argument"; return GH_E_BAD_ARG; }
+        hs[(size_t)i] = h;
+    }
+    const MsmOps* ops = ops_of(hs[0]->curve);
+    if (!ops) return GH_E_BAD_ARG;
+    int rc = ensure_init();
+    if (rc) return rc;
+    rc = ops->batch(hs.data(), d_scalars, n_scalars, count, out_xyz);
+    if (rc) {   // leave no stage of a failed pipeline in flight
+        hipStreamSynchronize(g.stream); hipStreamSynchronize(g.stream_acc); hipStreamSynchronize(g.stream_red);
+    }
+    return rc;
+}
+
 int gh_msm_resident(gh_bases_t handle, const uint64_t* scalars, size_t n_scalars, uint64_t* out_xyz) {
     void* d_s = nullptr;
     size_t n = 0;
@@ -245,6 +282,12 @@ int gh_msm_set_window(int c) {
 int gh_msm_get_window(gh_curve_t curve, size_t n) {
     std::lock_guard<std::mutex> lk(g_mu);
     return auto_window(n, curve == GH_MNT4753_G2 ? 2 : (curve == GH_MNT6753_G2 ? 3 : 1));
+}
+int gh_msm_batch_timing(int index, gh_msm_timing_t* out) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (index < 0 || (size_t)index >= g.batch_tm.size()) { g_err = "no such MSM in the last batch"; return GH_E_BAD_ARG; }
+    if (out) *out = g.batch_tm[(size_t)index];
+    return GH_OK;
 }
 int gh_msm_last_timing(gh_msm_timing_t* out) {
     std::lock_guard<std::mutex> lk(g_mu);

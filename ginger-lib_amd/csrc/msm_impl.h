@@ -273,171 +273,217 @@ void fold_merged(const std::vector<Proj<C>>& hw, int Wp, int q, int u, uint64_t*
     }
 }
 
+// One MSM as a sequence of stages, so that several MSMs can be pipelined over HIP streams
+// (msm_batch below): sort -> [host reads the chunk plan] -> accumulate -> reduce -> [host fold].
+// Every stage works on the buffers of one of two slots.
 template <class C>
-int msm_run(BasesBase* h, const void* d_scalars, size_t n_scalars, uint64_t* out_xyz) {
-    size_t n = h->n < n_scalars ? h->n : n_scalars;
-    auto t_begin = std::chrono::steady_clock::now();
+struct MsmJob {
+    BasesBase* h = nullptr;
+    const void* d_scalars = nullptr;
+    uint64_t* out_xyz = nullptr;
+    size_t n = 0;
+    int slot = 0;
+    bool merged = false;
+    int c = 0, W = 0, top_unsigned = 0, RW = 0, L1 = 0, L2 = 0;
+    uint32_t nb = 0, Q = 0, win_stride = 0, segs_per_window = 0, heavy_thr = 0, heavy_chunk = 0;
+    size_t total = 0, slots = 0, max_heavy = 0, max_chunks = 0;
+    uint32_t n_heavy = 0, n_chunks = 0;
+    int32_t* digits = nullptr;
+    uint32_t *counts = nullptr, *starts = nullptr, *cursor = nullptr, *sorted = nullptr, *order = nullptr, *size_hist = nullptr,
+             *size_cursor = nullptr, *chunk_start = nullptr, *plan = nullptr;
+    Proj<C>*buckets = nullptr, *seg_out = nullptr, *win_out = nullptr, *partials = nullptr;
+    uint32_t* hplan = nullptr;      // pinned
+    Proj<C>* hw = nullptr;          // pinned, 9 RW points
+    Aff<C>* salts = nullptr;
+    std::chrono::steady_clock::time_point t_begin;
     gh_msm_timing_t tm{};
-    if (n == 0) {
-        proj_to_abi_host<C>(out_xyz, proj_zero<C>());
-        g.last_msm = tm;
+
+    static int pinned(int slot, int which, size_t bytes, void** out) {
+        static void* p[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+        static size_t cap[2][2] = {{0, 0}, {0, 0}};
+        if (cap[slot][which] < bytes) {
+            if (p[slot][which]) HIPCHK(hipHostFree(p[slot][which]));
+            p[slot][which] = nullptr; cap[slot][which] = 0;
+            HIPCHK(hipHostMalloc(&p[slot][which], bytes + 256, hipHostMallocDefault));
+            cap[slot][which] = bytes + 256;
+        }
+        *out = p[slot][which];
         return GH_OK;
     }
-    // merged: the key carries a precomputed shift table -> all windows share one bucket set
-    const bool merged = h->d_table != nullptr && (g.window_override == 0 || g.window_override == h->pre_c);
-    const int c = merged ? h->pre_c : auto_window(n, C::F::DEG);
-    // after sign folding the scalar magnitudes are below 2^752 (msm_kernels.h, digits kernel)
-    const int W = 752 / c + 1;
-    const int top_unsigned = (!merged && 752 % c == 0 && W >= 2) ? 1 : 0;
-    const uint32_t nb = (1u << (c - 1)) + 1;
-    // bucket sets the reduction sees: W windows of nb slots, or (merged) Wp pseudo-windows of Q slots
-    const int q = 15;
-    const uint32_t Q = merged ? (nb <= (1u << q) + 1 ? nb : (1u << q)) : nb;
-    const int RW = merged ? (int)((nb + Q - 1) / Q) : W;
-    const size_t total = merged ? (size_t)nb : (size_t)W * nb;          // buckets that exist
-    const size_t slots = (size_t)RW * Q;                                // bucket array incl. padding
-    const uint32_t win_stride = merged ? 0u : nb;
-    static const int env_L1 = getenv("GH_REDUCE_L") ? atoi(getenv("GH_REDUCE_L")) : 0;
-    // items per lane, level 1 (power of two).  The wave programs are latency chains (2 L1 + 17 steps,
-    // then 2 L2 + 17): as long as the launch stays within one wave per SIMD (1024 on MI355X) a shorter
-    // L1 only shortens the chain; beyond that the steps of co-resident waves add up again
-    // (measured at 2^20 buckets: L1 = 16 -> 6.2 ms, 8 -> 6.8, 4 -> 8.2, 32 -> 7.9).
-    int L1 = MSM_REDUCE_L;
-    // (Fq3 stays at 16: its out-of-line products make the steps scratch-bandwidth bound, and more,
-    //  shorter programs were measured slower: 62.8 ms vs 58.7 ms at 2^17 buckets)
-    while (C::F::DEG < 3 && L1 > 4 && (size_t)RW * ((Q + 32u * L1 - 1) / (32u * L1)) <= 1024) L1 >>= 1;
-    if (env_L1 == 4 || env_L1 == 8 || env_L1 == 16 || env_L1 == 32) L1 = env_L1;
-    const uint32_t seg_slots = 64 * (uint32_t)L1;
-    const uint32_t segs_per_window = (Q + seg_slots - 1) / seg_slots;
-    const int L2 = (int)((segs_per_window + 63) / 64);             // items per lane, level 2 (one wave per window)
-    if ((size_t)W * n >= ((size_t)1 << 32) || total >= ((size_t)1 << 31)) {
-        g_err = "MSM too large for 32-bit bucket offsets";
-        return GH_E_UNSUPPORTED;
-    }
-    // salt points S0 = G, S1 = 2G (internal affine form) for the accumulate kernel's detour
-    static Aff<C>* salts = nullptr;
-    if (!salts) {
-        Aff<C> hs[2];
-        if (int src = make_salts<C>(hs)) return src;
-        HIPCHK(hipMalloc((void**)&salts, sizeof(hs)));
-        HIPCHK(hipMemcpy(salts, hs, sizeof(hs), hipMemcpyHostToDevice));
-    }
-    // Heavy threshold.  Buckets are walked longest first, one per thread at ~78 us per addition
-    // (2 waves / SIMD), so a bucket of s entries is free as long as s * 78 us stays well inside the
-    // kernel's own duration (~ W n / 1.65e9 s); beyond that it would be the tail, and is split.
-    // (merged windows: at least twice the mean bucket W n / 2^(c-1), so that chunking stays the exception)
-    uint32_t heavy_thr = merged ? (uint32_t)((2 * (size_t)W * n) >> (c - 1)) : (uint32_t)((4 * n) >> (c - 1));
-    {
-        const uint32_t by_duration = (uint32_t)((double)W * (double)n * 3.1e-6);
-        if (heavy_thr < by_duration) heavy_thr = by_duration;
-    }
-    if (heavy_thr < 128) heavy_thr = 128;
-    if (heavy_thr > (uint32_t)MSM_MAX_HEAVY_THRESHOLD) heavy_thr = MSM_MAX_HEAVY_THRESHOLD;
-    const size_t max_heavy = ((size_t)W * n) / (heavy_thr + 1) + 1;          // buckets with > thr entries
-    const uint32_t heavy_chunk = heavy_thr;                                  // chunk = a bucket of threshold size
-    const size_t max_chunks = ((size_t)W * n) / heavy_chunk + max_heavy + 1;
-    int32_t* digits; uint32_t *counts, *starts, *cursor, *sorted, *order, *size_hist, *size_cursor, *chunk_start, *plan;
-    Proj<C>*buckets, *seg_out, *win_out, *partials;
-    int rc;
-#define POOL(name, ptr, bytes) if ((rc = pool_get(name, bytes, (void**)&ptr))) return rc;
-    POOL("digits", digits, (size_t)W * n * 4)
-    POOL("counts", counts, total * 4)
-    POOL("starts", starts, total * 4)
-    POOL("cursor", cursor, total * 4)
-    POOL("sorted", sorted, (size_t)W * n * 4)
-    POOL("order", order, total * 4)
-    POOL("size_hist", size_hist, MSM_SIZE_BINS * 4)
-    POOL("size_cursor", size_cursor, MSM_SIZE_BINS * 4)
-    POOL("chunk_start", chunk_start, (max_heavy + 2) * 4)
-    POOL("plan", plan, 16)
-    POOL("buckets", buckets, slots * sizeof(Proj<C>))
-    POOL("seg_out", seg_out, (size_t)RW * segs_per_window * 3 * sizeof(Proj<C>))
-    POOL("win_out", win_out, (size_t)3 * RW * 3 * sizeof(Proj<C>))
+
+    int prepare(BasesBase* h_, const void* d_scalars_, size_t n_scalars, uint64_t* out, int slot_) {
+        h = h_; d_scalars = d_scalars_; out_xyz = out; slot = slot_;
+        n = h->n < n_scalars ? h->n : n_scalars;
+        t_begin = std::chrono::steady_clock::now();
+        if (n == 0) return GH_OK;
+        // merged: the key carries a precomputed shift table -> all windows share one bucket set
+        merged = h->d_table != nullptr && (g.window_override == 0 || g.window_override == h->pre_c);
+        c = merged ? h->pre_c : auto_window(n, C::F::DEG);
+        // after sign folding the scalar magnitudes are below 2^752 (msm_kernels.h, digits kernel)
+        W = 752 / c + 1;
+        top_unsigned = (!merged && 752 % c == 0 && W >= 2) ? 1 : 0;
+        nb = (1u << (c - 1)) + 1;
+        // bucket sets the reduction sees: W windows of nb slots, or (merged) RW pseudo-windows of Q slots
+        const int q = 15;
+        Q = merged ? (nb <= (1u << q) + 1 ? nb : (1u << q)) : nb;
+        RW = merged ? (int)((nb + Q - 1) / Q) : W;
+        total = merged ? (size_t)nb : (size_t)W * nb;          // buckets that exist
+        slots = (size_t)RW * Q;                                // bucket array incl. padding
+        win_stride = merged ? 0u : nb;
+        static const int env_L1 = getenv("GH_REDUCE_L") ? atoi(getenv("GH_REDUCE_L")) : 0;
+        // items per lane, level 1 (power of two).  The wave programs are latency chains (2 L1 + 17 steps,
+        // then 2 L2 + 17): as long as the launch stays within one wave per SIMD (1024 on MI355X) a shorter
+        // L1 only shortens the chain; beyond that the steps of co-resident waves add up again
+        // (measured at 2^20 buckets: L1 = 16 -> 6.2 ms, 8 -> 6.8, 4 -> 8.2, 32 -> 7.9).
+        L1 = MSM_REDUCE_L;
+        // (Fq3 stays at 16: its out-of-line products make the steps scratch-bandwidth bound, and more,
+        //  shorter programs were measured slower: 62.8 ms vs 58.7 ms at 2^17 buckets)
+        while (C::F::DEG < 3 && L1 > 4 && (size_t)RW * ((Q + 32u * L1 - 1) / (32u * L1)) <= 1024) L1 >>= 1;
+        if (env_L1 == 4 || env_L1 == 8 || env_L1 == 16 || env_L1 == 32) L1 = env_L1;
+        const uint32_t seg_slots = 64 * (uint32_t)L1;
+        segs_per_window = (Q + seg_slots - 1) / seg_slots;
+        L2 = (int)((segs_per_window + 63) / 64);               // items per lane, level 2 (one wave per window)
+        if ((size_t)W * n >= ((size_t)1 << 31) || total >= ((size_t)1 << 31)) {
+            g_err = "MSM too large for 31-bit list entries";
+            return GH_E_UNSUPPORTED;
+        }
+        // salt points S0 = G, S1 = 2G (internal affine form) for the accumulate kernel's detour
+        static Aff<C>* d_salts = nullptr;
+        if (!d_salts) {
+            Aff<C> hs[2];
+            if (int src = make_salts<C>(hs)) return src;
+            HIPCHK(hipMalloc((void**)&d_salts, sizeof(hs)));
+            HIPCHK(hipMemcpy(d_salts, hs, sizeof(hs), hipMemcpyHostToDevice));
+        }
+        salts = d_salts;
+        // Heavy threshold.  Buckets are walked longest first, one per thread at ~78 us per addition
+        // (2 waves / SIMD), so a bucket of s entries is free as long as s * 78 us stays well inside the
+        // kernel's own duration (~ W n / 1.65e9 s); beyond that it would be the tail, and is split.
+        // (merged windows: at least twice the mean bucket W n / 2^(c-1), so that chunking stays the exception)
+        heavy_thr = merged ? (uint32_t)((2 * (size_t)W * n) >> (c - 1)) : (uint32_t)((4 * n) >> (c - 1));
+        {
+            const uint32_t by_duration = (uint32_t)((double)W * (double)n * 3.1e-6);
+            if (heavy_thr < by_duration) heavy_thr = by_duration;
+        }
+        if (heavy_thr < 128) heavy_thr = 128;
+        if (heavy_thr > (uint32_t)MSM_MAX_HEAVY_THRESHOLD) heavy_thr = MSM_MAX_HEAVY_THRESHOLD;
+        max_heavy = ((size_t)W * n) / (heavy_thr + 1) + 1;          // buckets with > thr entries
+        heavy_chunk = heavy_thr;                                    // chunk = a bucket of threshold size
+        max_chunks = ((size_t)W * n) / heavy_chunk + max_heavy + 1;
+        int rc;
+        char nm[48];
+#define POOL(name, ptr, bytes)                                      \
+    snprintf(nm, sizeof nm, "%s#%d", name, slot);                   \
+    if ((rc = pool_get(nm, bytes, (void**)&ptr))) return rc;
+        POOL("digits", digits, (size_t)W * n * 4)
+        POOL("counts", counts, total * 4)
+        POOL("starts", starts, total * 4)
+        POOL("cursor", cursor, total * 4)
+        POOL("sorted", sorted, (size_t)W * n * 4)
+        POOL("order", order, total * 4)
+        POOL("size_hist", size_hist, MSM_SIZE_BINS * 4)
+        POOL("size_cursor", size_cursor, MSM_SIZE_BINS * 4)
+        POOL("chunk_start", chunk_start, (max_heavy + 2) * 4)
+        POOL("plan", plan, 16)
+        POOL("buckets", buckets, slots * sizeof(Proj<C>))
+        POOL("seg_out", seg_out, (size_t)RW * segs_per_window * 3 * sizeof(Proj<C>))
+        POOL("win_out", win_out, (size_t)3 * RW * 3 * sizeof(Proj<C>))
 #undef POOL
-    hipStream_t st = g.stream;
-    static const bool dbg = getenv("GH_DEBUG") != nullptr;
-#define TRACE(msg)                                                                   \
-    if (dbg) {                                                                       \
-        HIPCHK(hipStreamSynchronize(st));                                            \
-        fprintf(stderr, "[gh] msm %s (n=%zu c=%d W=%d)\n", msg, n, c, W);            \
-        fflush(stderr);                                                              \
+        if ((rc = pinned(slot, 0, 16, (void**)&hplan))) return rc;
+        if ((rc = pinned(slot, 1, (size_t)9 * RW * sizeof(Proj<C>), (void**)&hw))) return rc;
+        return GH_OK;
     }
-    TRACE("begin")
-    HIPCHK(hipEventRecord(g.ev[0], st));
-    HIPCHK(hipMemsetAsync(counts, 0, total * 4, st));
-    HIPCHK(hipMemsetAsync(size_hist, 0, MSM_SIZE_BINS * 4, st));
-    hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
-                       (const uint32_t*)d_scalars, (const uint8_t*)h->d_inf, n, c, W, win_stride, top_unsigned, scalar_modulus<C>(), digits, counts);
-    HIPCHK(hipGetLastError());
-    TRACE("digits done")
-    if ((rc = device_scan(counts, starts, total, "scan_tmp"))) return rc;
-    TRACE("scan done")
-    HIPCHK(hipMemcpyAsync(cursor, starts, total * 4, hipMemcpyDeviceToDevice, st));
-    hipLaunchKernelGGL(msm_size_hist_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, counts, total, heavy_thr, size_hist);
-    if ((rc = device_scan(size_hist, size_cursor, MSM_SIZE_BINS, "scan_tmp2"))) return rc;
-    hipLaunchKernelGGL(msm_size_scatter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, counts, total, heavy_thr, size_cursor, order);
-    hipLaunchKernelGGL(msm_heavy_plan_kernel, dim3(1), dim3(1), 0, st, (const uint32_t*)size_hist, (const uint32_t*)counts,
-                       (const uint32_t*)order, heavy_chunk, chunk_start, plan);
-    hipLaunchKernelGGL(msm_scatter_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)W), dim3(256), 0, st,
-                       (const int32_t*)digits, n, W, win_stride, merged ? (uint32_t)h->n : 0u, cursor, sorted);
-    if (slots > total)   // padding slots of the last pseudo-window: infinity (Z = 0)
-        HIPCHK(hipMemsetAsync((void*)(buckets + total), 0, (slots - total) * sizeof(Proj<C>), st));
-    HIPCHK(hipGetLastError());
-    TRACE("scatter done")
-    uint32_t hplan[2] = {0, 0};
-    HIPCHK(hipMemcpyAsync(hplan, plan, 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipEventRecord(g.ev[1], st));
-    HIPCHK(hipStreamSynchronize(st));
-    const uint32_t n_heavy = hplan[0], n_chunks = hplan[1];
-    if (n_heavy > max_heavy || n_chunks > max_chunks) { g_err = "internal: heavy-bucket plan out of range"; return GH_E_HIP; }
-    const size_t lds_wave = 64 * sizeof(Proj<C>);
-    partials = nullptr;
-    if (n_heavy > 0 && (rc = pool_get("partials", (size_t)n_chunks * sizeof(Proj<C>), (void**)&partials))) return rc;
-    // 2 waves / SIMD (256 VGPRs, 184 B scratch) measured 29.3 ms vs 34.6 ms for 1 wave (297 registers) at 2^20
-    static const int acc_waves = getenv("GH_ACC_WAVES") ? atoi(getenv("GH_ACC_WAVES")) : 2;
-    const void* src_points = merged ? h->d_table : h->d_points;
-    HIPCHK(hipEventRecord(g.ev[2], st));
-    {
-        // one launch: the chunks of the heavy buckets first, then every other bucket, longest first
-        const size_t tasks = (size_t)n_chunks + (total - n_heavy);
-        static const bool no_split = getenv("GH_NO_SPLIT") != nullptr;
-        // G2: one coefficient per lane, 2 (Fq2) / 3 (Fq3) lanes per task (msm_kernels.h 4b)
-        constexpr bool is_g2 = std::is_same<C, Mnt4G2>::value || std::is_same<C, Mnt6G2>::value;
-        if constexpr (is_g2) {
-            if (!no_split) {   // Fq2 / Fq3: one coefficient per lane, 2 / 3 lanes per task (msm_kernels.h 4b)
-                typedef typename std::conditional<std::is_same<C, Mnt4G2>::value, F2S<P4, 13>, F3S<P6, 11>>::type FS;
-                constexpr int LANES = FS::LANES;
-                const size_t waves = (tasks + (64 / LANES) - 1) / (64 / LANES);
-                hipLaunchKernelGGL((msm_accumulate_split_kernel<C, FS, LANES>), dim3((unsigned)((waves * 64 + 255) / 256)), dim3(256), 0, st,
-                                   (const Aff<C>*)src_points, (const uint32_t*)sorted, (const uint32_t*)starts,
-                                   (const uint32_t*)counts, (const uint32_t*)order, (uint32_t)total, (const Aff<C>*)salts, buckets,
-                                   (const uint32_t*)chunk_start, n_heavy, n_chunks, heavy_chunk, partials);
+
+    // stage 1 (stream st): digits + histogram, scan, bucket order by size, heavy plan, scatter; plan -> host
+    int launch_sort(hipStream_t st) {
+        if (n == 0) return GH_OK;
+        int rc;
+        HIPCHK(hipEventRecord(g.pev[slot][0], st));
+        HIPCHK(hipMemsetAsync(counts, 0, total * 4, st));
+        HIPCHK(hipMemsetAsync(size_hist, 0, MSM_SIZE_BINS * 4, st));
+        hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                           (const uint32_t*)d_scalars, (const uint8_t*)h->d_inf, n, c, W, win_stride, top_unsigned, scalar_modulus<C>(), digits, counts);
+        HIPCHK(hipGetLastError());
+        if ((rc = device_scan(counts, starts, total, "scan_tmp"))) return rc;
+        HIPCHK(hipMemcpyAsync(cursor, starts, total * 4, hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL(msm_size_hist_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, counts, total, heavy_thr, size_hist);
+        if ((rc = device_scan(size_hist, size_cursor, MSM_SIZE_BINS, "scan_tmp2"))) return rc;
+        hipLaunchKernelGGL(msm_size_scatter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, counts, total, heavy_thr, size_cursor, order);
+        hipLaunchKernelGGL(msm_heavy_plan_kernel, dim3(1), dim3(1), 0, st, (const uint32_t*)size_hist, (const uint32_t*)counts,
+                           (const uint32_t*)order, (const uint32_t*)starts, (uint32_t)total, heavy_chunk, chunk_start, plan);
+        hipLaunchKernelGGL(msm_scatter_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)W), dim3(256), 0, st,
+                           (const int32_t*)digits, n, W, win_stride, merged ? (uint32_t)h->n : 0u, cursor, sorted);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(hplan, plan, 16, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipEventRecord(g.pev[slot][1], st));
+        return GH_OK;
+    }
+
+    // stage 2 (stream st): waits on the host for the plan of stage 1, then the accumulation launch
+    int launch_accumulate(hipStream_t st) {
+        if (n == 0) return GH_OK;
+        int rc;
+        HIPCHK(hipEventSynchronize(g.pev[slot][1]));
+        n_heavy = hplan[0]; n_chunks = hplan[1];
+        tm.accumulate_madds = hplan[2];
+        if (n_heavy > max_heavy || n_chunks > max_chunks) { g_err = "internal: heavy-bucket plan out of range"; return GH_E_HIP; }
+        const size_t lds_wave = 64 * sizeof(Proj<C>);
+        partials = nullptr;
+        char nm[48];
+        snprintf(nm, sizeof nm, "partials#%d", slot);
+        if (n_heavy > 0 && (rc = pool_get(nm, (size_t)n_chunks * sizeof(Proj<C>), (void**)&partials))) return rc;
+        // 2 waves / SIMD (256 VGPRs, 184 B scratch) measured 29.3 ms vs 34.6 ms for 1 wave (297 registers) at 2^20
+        static const int acc_waves = getenv("GH_ACC_WAVES") ? atoi(getenv("GH_ACC_WAVES")) : 2;
+        const void* src_points = merged ? h->d_table : h->d_points;
+        if (slots > total)   // padding slots of the last pseudo-window: infinity (Z = 0)
+            HIPCHK(hipMemsetAsync((void*)(buckets + total), 0, (slots - total) * sizeof(Proj<C>), st));
+        HIPCHK(hipEventRecord(g.pev[slot][2], st));
+        {
+            // one launch: the chunks of the heavy buckets first, then every other bucket, longest first
+            const size_t tasks = (size_t)n_chunks + (total - n_heavy);
+            static const bool no_split = getenv("GH_NO_SPLIT") != nullptr;
+            // G2: one coefficient per lane, 2 (Fq2) / 3 (Fq3) lanes per task (msm_kernels.h 4b)
+            constexpr bool is_g2 = std::is_same<C, Mnt4G2>::value || std::is_same<C, Mnt6G2>::value;
+            if constexpr (is_g2) {
+                if (!no_split) {
+                    typedef typename std::conditional<std::is_same<C, Mnt4G2>::value, F2S<P4, 13>, F3S<P6, 11>>::type FS;
+                    constexpr int LANES = FS::LANES;
+                    const size_t waves = (tasks + (64 / LANES) - 1) / (64 / LANES);
+                    hipLaunchKernelGGL((msm_accumulate_split_kernel<C, FS, LANES>), dim3((unsigned)((waves * 64 + 255) / 256)), dim3(256), 0, st,
+                                       (const Aff<C>*)src_points, (const uint32_t*)sorted, (const uint32_t*)starts,
+                                       (const uint32_t*)counts, (const uint32_t*)order, (uint32_t)total, (const Aff<C>*)salts, buckets,
+                                       (const uint32_t*)chunk_start, n_heavy, n_chunks, heavy_chunk, partials);
+                }
+            }
+            if (!(is_g2 && !no_split)) {
+                if (acc_waves >= 2)
+                    hipLaunchKernelGGL((msm_accumulate_kernel<C, 2>), dim3((unsigned)((tasks + 255) / 256)), dim3(256), 0, st,
+                                       (const Aff<C>*)src_points, (const uint32_t*)sorted, (const uint32_t*)starts,
+                                       (const uint32_t*)counts, (const uint32_t*)order, (uint32_t)total, (const Aff<C>*)salts, buckets,
+                                       (const uint32_t*)chunk_start, n_heavy, n_chunks, heavy_chunk, partials);
+                else
+                    hipLaunchKernelGGL((msm_accumulate_kernel<C, 1>), dim3((unsigned)((tasks + 255) / 256)), dim3(256), 0, st,
+                                       (const Aff<C>*)src_points, (const uint32_t*)sorted, (const uint32_t*)starts,
+                                       (const uint32_t*)counts, (const uint32_t*)order, (uint32_t)total, (const Aff<C>*)salts, buckets,
+                                       (const uint32_t*)chunk_start, n_heavy, n_chunks, heavy_chunk, partials);
             }
         }
-        if (!(is_g2 && !no_split)) {
-        if (acc_waves >= 2)
-            hipLaunchKernelGGL((msm_accumulate_kernel<C, 2>), dim3((unsigned)((tasks + 255) / 256)), dim3(256), 0, st,
-                               (const Aff<C>*)src_points, (const uint32_t*)sorted, (const uint32_t*)starts,
-                               (const uint32_t*)counts, (const uint32_t*)order, (uint32_t)total, (const Aff<C>*)salts, buckets,
-                               (const uint32_t*)chunk_start, n_heavy, n_chunks, heavy_chunk, partials);
-        else
-            hipLaunchKernelGGL((msm_accumulate_kernel<C, 1>), dim3((unsigned)((tasks + 255) / 256)), dim3(256), 0, st,
-                               (const Aff<C>*)src_points, (const uint32_t*)sorted, (const uint32_t*)starts,
-                               (const uint32_t*)counts, (const uint32_t*)order, (uint32_t)total, (const Aff<C>*)salts, buckets,
-                               (const uint32_t*)chunk_start, n_heavy, n_chunks, heavy_chunk, partials);
-        }
-    }
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(g.ev[3], st));
-    TRACE("accumulate done")
-    if (n_heavy > 0) {   // one wave per heavy bucket adds its chunk sums
-        hipLaunchKernelGGL((msm_heavy_combine_kernel<C>), dim3(n_heavy), dim3(64), lds_wave, st, (const Proj<C>*)partials,
-                           (const uint32_t*)order, (const uint32_t*)chunk_start, buckets);
         HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(g.pev[slot][3], st));
+        if (n_heavy > 0) {   // one wave per heavy bucket adds its chunk sums
+            hipLaunchKernelGGL((msm_heavy_combine_kernel<C>), dim3(n_heavy), dim3(64), lds_wave, st, (const Proj<C>*)partials,
+                               (const uint32_t*)order, (const uint32_t*)chunk_start, buckets);
+            HIPCHK(hipGetLastError());
+        }
+        HIPCHK(hipEventRecord(g.pev[slot][4], st));
+        return GH_OK;
     }
-    HIPCHK(hipEventRecord(g.ev[4], st));
-    TRACE("heavy done")
-    {   // level 1: one wave per segment of 64 * L1 bucket slots -> (runW, A, Bv) per segment
+
+    // stage 3 (stream st): the two wave-program levels of the bucket reduction; window sums -> host
+    int launch_reduce(hipStream_t st) {
+        if (n == 0) return GH_OK;
+        const size_t lds_wave = 64 * sizeof(Proj<C>);
+        // level 1: one wave per segment of 64 * L1 bucket slots -> (runW, A, Bv) per segment
         WaveReduceIn<C> i0{buckets, 1, 0, Q, 0, (uint32_t)total}, none{nullptr, 0, 0, 0, 0, 0};
         static const int env_wpb = getenv("GH_REDUCE_WPB") ? atoi(getenv("GH_REDUCE_WPB")) : 1;
         int wpb = env_wpb >= 1 && (size_t)env_wpb * lds_wave <= 65536 && env_wpb <= 4 ? env_wpb : 1;   // waves per block
@@ -449,46 +495,93 @@ int msm_run(BasesBase* h, const void* d_scalars, size_t n_scalars, uint64_t* out
         WaveReduceIn<C> r0{seg_out, 3, 0, segs_per_window, 0, all}, r1{seg_out, 3, 1, segs_per_window, 1, all}, r2{seg_out, 3, 2, segs_per_window, 1, all};
         hipLaunchKernelGGL((msm_wave_reduce_kernel<C>), dim3((nb2 + wpb - 1) / wpb), dim3(64 * wpb), lds_wave * wpb, st,
                            r0, r1, r2, (uint32_t)RW, 3u, 1u, L2, (const Aff<C>*)salts, win_out);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(g.pev[slot][5], st));
+        HIPCHK(hipMemcpyAsync(hw, win_out, (size_t)9 * RW * sizeof(Proj<C>), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipEventRecord(g.pev[slot][6], st));
+        return GH_OK;
     }
-    HIPCHK(hipGetLastError());
-    TRACE("reduce done")
-    HIPCHK(hipEventRecord(g.ev[5], st));
-    std::vector<Proj<C>> hw((size_t)9 * RW);
-    HIPCHK(hipMemcpyAsync(hw.data(), win_out, hw.size() * sizeof(Proj<C>), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    auto t_fold0 = std::chrono::steady_clock::now();
-    // Window sum R_w = 64 PA + PB + U (64 PW + PS), U = 64 L1 = 2^u, with
-    //   PW, PS = (A, Bv) of the weighted level-2 program over the runW's, PA = sum A, PB = sum Bv.
-    // Horner over windows, high to low (variable_base.rs:73-82), with the powers of two of R_w
-    // merged into the c doublings between windows:
-    //   acc*2^c + R_w = (((acc*2^(c-u-6) + PW)*2^6 + PS)*2^(u-6) + PA)*2^6 + PB        (c >= u + 6)
-    int u = 6;
-    while ((1 << (u - 6)) < L1) u++;
-    if (merged) {
-        int lq = 0;
-        while ((1u << lq) < Q) lq++;            // RW > 1 only with Q = 2^q; for RW == 1 the term is empty
-        fold_merged<C>(hw, RW, lq, u, out_xyz);
-    } else {
-        fold_windows<C>(hw, W, c, u, top_unsigned, out_xyz);
+
+    // stage 4 (host): wait for the window sums, fold
+    int finish() {
+        if (n == 0) {
+            proj_to_abi_host<C>(out_xyz, proj_zero<C>());
+            g.last_msm = gh_msm_timing_t{};
+            g.batch_tm.push_back(g.last_msm);
+            return GH_OK;
+        }
+        HIPCHK(hipEventSynchronize(g.pev[slot][6]));
+        auto t_fold0 = std::chrono::steady_clock::now();
+        std::vector<Proj<C>> hwv(hw, hw + (size_t)9 * RW);
+        // Window sum R_w = 64 PA + PB + U (64 PW + PS), U = 64 L1 = 2^u, with
+        //   PW, PS = (A, Bv) of the weighted level-2 program over the runW's, PA = sum A, PB = sum Bv.
+        // Horner over windows, high to low (variable_base.rs:73-82), with the powers of two of R_w
+        // merged into the c doublings between windows:
+        //   acc*2^c + R_w = (((acc*2^(c-u-6) + PW)*2^6 + PS)*2^(u-6) + PA)*2^6 + PB        (c >= u + 6)
+        int u = 6;
+        while ((1 << (u - 6)) < L1) u++;
+        if (merged) {
+            int lq = 0;
+            while ((1u << lq) < Q) lq++;            // RW > 1 only with Q = 2^q; for RW == 1 the term is empty
+            fold_merged<C>(hwv, RW, lq, u, out_xyz);
+        } else {
+            fold_windows<C>(hwv, W, c, u, top_unsigned, out_xyz);
+        }
+        auto t_end = std::chrono::steady_clock::now();
+        HIPCHK(hipEventElapsedTime(&tm.sort_ms, g.pev[slot][0], g.pev[slot][1]));
+        HIPCHK(hipEventElapsedTime(&tm.accumulate_ms, g.pev[slot][2], g.pev[slot][3]));   // brackets exactly the accumulation launch
+        HIPCHK(hipEventElapsedTime(&tm.heavy_ms, g.pev[slot][3], g.pev[slot][4]));
+        HIPCHK(hipEventElapsedTime(&tm.reduce_ms, g.pev[slot][4], g.pev[slot][5]));
+        tm.heavy_buckets = n_heavy;
+        tm.fold_ms = std::chrono::duration<float, std::milli>(t_end - t_fold0).count();
+        tm.total_ms = std::chrono::duration<float, std::milli>(t_end - t_begin).count();
+        tm.window_bits = c;
+        tm.num_windows = W;
+        g.last_msm = tm;
+        g.batch_tm.push_back(tm);
+        return GH_OK;
     }
-    TRACE("fold done")
-#undef TRACE
-    auto t_end = std::chrono::steady_clock::now();
-    HIPCHK(hipEventElapsedTime(&tm.sort_ms, g.ev[0], g.ev[1]));
-    HIPCHK(hipEventElapsedTime(&tm.accumulate_ms, g.ev[2], g.ev[3]));   // brackets exactly msm_accumulate_kernel
-    HIPCHK(hipEventElapsedTime(&tm.heavy_ms, g.ev[3], g.ev[4]));
-    HIPCHK(hipEventElapsedTime(&tm.reduce_ms, g.ev[4], g.ev[5]));
-    tm.heavy_buckets = n_heavy;
-    tm.fold_ms = std::chrono::duration<float, std::milli>(t_end - t_fold0).count();
-    tm.total_ms = std::chrono::duration<float, std::milli>(t_end - t_begin).count();
-    tm.window_bits = c;
-    tm.num_windows = W;
-    uint32_t last_start = 0, last_count = 0;
-    HIPCHK(hipMemcpy(&last_start, starts + total - 1, 4, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(&last_count, counts + total - 1, 4, hipMemcpyDeviceToHost));
-    tm.accumulate_madds = (unsigned long long)last_start + last_count;
-    g.last_msm = tm;
-    return GH_OK;
+};
+
+// `count` MSMs back to back.  With count > 1 the stages are pipelined over three streams and two
+// buffer slots: while MSM k accumulates (stream_acc), the bucket sort of MSM k+1 (g.stream) and the
+// bucket reduction + host fold of MSM k-1 (stream_red, host) run beside it -- the sort is
+// atomics/memory bound and the reduction's wave programs are latency chains, so both fit into the
+// issue slots the accumulation leaves.  Slot reuse is ordered by events:
+//   sort(k+1) waits for acc(k-1) (lists of that slot), acc(k+1) for reduce(k-1) (its buckets).
+template <class C>
+int msm_batch(BasesBase* const* hs, const void* const* d_scalars, const size_t* n_scalars, int count, uint64_t* out_xyz) {
+    const size_t out_stride = (size_t)36 * C::F::DEG;
+    std::vector<MsmJob<C>> jobs((size_t)count);
+    int rc;
+    auto issue_sort = [&](int k) -> int {
+        MsmJob<C>& j = jobs[(size_t)k];
+        if ((rc = j.prepare(hs[k], d_scalars[k], n_scalars[k], out_xyz + (size_t)k * out_stride, k & 1))) return rc;
+        if (k >= 2) {
+            HIPCHK(hipStreamWaitEvent(g.stream, g.pev[k & 1][4], 0));   // acc(k-2) has consumed this slot's lists
+        }
+        return j.launch_sort(g.stream);
+    };
+    g.batch_tm.clear();
+    if (count <= 0) return GH_OK;
+    if ((rc = issue_sort(0))) return rc;
+    for (int k = 0; k < count; k++) {
+        MsmJob<C>& j = jobs[(size_t)k];
+        if (k >= 2 && j.n) HIPCHK(hipStreamWaitEvent(g.stream_acc, g.pev[k & 1][6], 0));   // reduce(k-2) is done with this slot's buckets
+        if ((rc = j.launch_accumulate(g.stream_acc))) return rc;
+        if (j.n) HIPCHK(hipStreamWaitEvent(g.stream_red, g.pev[k & 1][4], 0));
+        if ((rc = j.launch_reduce(g.stream_red))) return rc;
+        // finish(k-1) before sort(k+1): they share a slot (stage events, pinned buffers).  The host waits
+        // here for reduce(k-1), a few ms into acc(k); sort(k+1) still has most of acc(k) to hide behind.
+        if (k >= 1 && (rc = jobs[(size_t)k - 1].finish())) return rc;
+        if (k + 1 < count && (rc = issue_sort(k + 1))) return rc;
+    }
+    return jobs[(size_t)count - 1].finish();
+}
+
+template <class C>
+int msm_run(BasesBase* h, const void* d_scalars, size_t n_scalars, uint64_t* out_xyz) {
+    return msm_batch<C>(&h, &d_scalars, &n_scalars, 1, out_xyz);
 }
 
 template <class C>
@@ -542,7 +635,7 @@ template <class C> int to_affine_host(const uint64_t* xyz, uint64_t* out_xy, uin
     const MsmOps* NAME() {                                                                     \
         static const MsmOps ops = {&upload_bases<CURVE>, &msm_run<CURVE>, &msm_host<CURVE>,    \
                                    &proj_add_host<CURVE>, &to_affine_host<CURVE>,              \
-                                   &precompute_bases<CURVE>};                                  \
+                                   &precompute_bases<CURVE>, &msm_batch<CURVE>};               \
         return &ops;                                                                           \
     }                                                                                          \
     }

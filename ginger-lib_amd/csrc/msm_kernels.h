@@ -341,9 +341,10 @@ msm_size_scatter_kernel(const uint32_t* counts, size_t total, uint32_t heavy_thr
     if (g < total) order[h[bin] + rank] = (uint32_t)g;
 }
 
-// plan[0] = n_heavy, plan[1] = total number of chunks; chunk_start[h] for h in [0, n_heavy]
+// plan[0] = n_heavy, plan[1] = total number of chunks, plan[2] = list entries; chunk_start[h] for h in [0, n_heavy]
 static __global__ void msm_heavy_plan_kernel(const uint32_t* size_hist, const uint32_t* counts, const uint32_t* order,
-                                             uint32_t chunk, uint32_t* chunk_start, uint32_t* plan) {
+                                             const uint32_t* starts, uint32_t total, uint32_t chunk, uint32_t* chunk_start,
+                                             uint32_t* plan) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const uint32_t n_heavy = size_hist[0];
     uint32_t run = 0;
@@ -354,6 +355,8 @@ static __global__ void msm_heavy_plan_kernel(const uint32_t* size_hist, const ui
     chunk_start[n_heavy] = run;
     plan[0] = n_heavy;
     plan[1] = run;
+    plan[2] = starts[total - 1] + counts[total - 1];   // list entries = additions the accumulation will issue
+    plan[3] = 0;
 }
 
 // ---------------------------------------------------------------- 3. scatter

@@ -7,6 +7,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <vector>
 #include "../../include/ginger_hip.h"
 #include "fp29.h"
 
@@ -29,12 +30,16 @@ struct DevBuf {
 struct Ctx {
     bool ready = false;
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;       // transforms, bucket sort
+    hipStream_t stream_acc = nullptr;   // MSM accumulation (lowest priority: the filler of the pipeline)
+    hipStream_t stream_red = nullptr;   // MSM bucket reduction (highest priority: short latency chains)
     hipEvent_t ev[8];
+    hipEvent_t pev[2][8];               // MSM stage events per pipeline slot
     std::map<int, Domain> domains[2];
     std::map<std::string, DevBuf> pool;
     int window_override = 0;
     gh_msm_timing_t last_msm{};
+    std::vector<gh_msm_timing_t> batch_tm;   // per-MSM timings of the last batch call
     float last_fft_ms = 0;
 };
 
@@ -75,6 +80,7 @@ struct MsmOps {
     int (*proj_add)(uint64_t* acc_xyz, const uint64_t* p_xyz);
     int (*to_affine)(const uint64_t* xyz, uint64_t* out_xy, uint8_t* is_infinity);
     int (*precompute)(BasesBase* h, int window_bits);
+    int (*batch)(BasesBase* const* hs, const void* const* d_scalars, const size_t* n_scalars, int count, uint64_t* out_xyz);
 };
 const MsmOps* msm_ops_mnt4753_g1();
 const MsmOps* msm_ops_mnt4753_g2();

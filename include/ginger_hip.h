@@ -108,6 +108,15 @@ int gh_msm_resident(gh_bases_t handle, const uint64_t* scalars, size_t n_scalars
  * and by a device-resident prover pipeline.  The call is synchronous on the library stream. */
 int gh_msm_resident_dev(gh_bases_t handle, const void* d_scalars, size_t n_scalars, uint64_t* out_xyz);
 
+/* `count` MSMs on one curve, back to back: out_xyz + i * (36 * deg) receives
+ *   sum_j d_scalars[i][j] * bases(handles[i])[j]            (each exactly as gh_msm_resident_dev).
+ * The prover issues its large MSMs in sequence (groth16/prover.rs:273-325: a_query, b_g1_query,
+ * h_query, l_query on G1); given as one batch, the library pipelines them over HIP streams: the
+ * bucket sort of MSM i+1 and the bucket reduction + window fold of MSM i-1 run beside the
+ * accumulation of MSM i.  handles may repeat; results do not depend on the batching.           */
+int gh_msm_resident_dev_batch(const gh_bases_t* handles, const void* const* d_scalars, const size_t* n_scalars, int count,
+                              uint64_t* out_xyz);
+
 /* Window size override for sweeps (0 = automatic).  Affects subsequent MSM calls. */
 int gh_msm_set_window(int c);
 int gh_msm_get_window(gh_curve_t curve, size_t n);
@@ -127,6 +136,9 @@ typedef struct {
     unsigned int heavy_buckets;
 } gh_msm_timing_t;
 int gh_msm_last_timing(gh_msm_timing_t* out);
+/* the same for MSM `index` of the last gh_msm_resident_dev_batch call (device phases of neighbouring
+ * MSMs overlap there, so the phases of one MSM no longer add up to its share of the wall time) */
+int gh_msm_batch_timing(int index, gh_msm_timing_t* out);
 
 /* ---- evaluation-domain transforms -------------------------------------------------------- */
 /* 1 if EvaluationDomain::new(num_coeffs) would be Some(..) (domain.rs:65-72), else 0;

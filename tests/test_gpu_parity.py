@@ -348,3 +348,46 @@ def test_msm_precomputed_skewed_and_large(gpu):
     assert gpu.msm_last_timing()["num_windows"] == 58
     gpu.msm_set_window(0)
     rb.free()
+
+
+def test_msm_batch_pipelined(gpu):
+    """gh_msm_resident_dev_batch: several MSMs pipelined over streams (two buffer slots) give exactly
+    the results of the same MSMs issued one by one -- different keys, lengths (incl. empty), with and
+    without a shift table, more jobs than slots."""
+    curve = "mnt4753_g1"
+    C = pyref.CURVES[curve]
+    rng = pyref.Rng(99)
+    pool = S.chain_points(C, 128, rng)
+    keys, scal = [], []
+    for i, n in enumerate((500, 128, 1000, 64, 777, 300, 2000)):
+        pts = [pool[(j * (i + 3)) % 128] for j in range(n)]
+        b, inf = S.bases_array(C, pts)
+        rb = gpu.ResidentBases(curve, b, inf)
+        if i % 3 != 1:
+            rb.precompute(0 if i % 2 else 13)
+        s = S.scalar_array([rng.field_elem(C.order) for _ in range(n)])
+        keys.append((rb, b, inf))
+        scal.append(s)
+    jobs, expected = [], []
+    bufs = []
+    for i, ((rb, b, inf), s) in enumerate(zip(keys, scal)):
+        m = 0 if i == 3 else (len(s) if i % 2 == 0 else len(s) // 2)
+        d = gpu.DeviceBuffer(max(96, s.nbytes)).upload(s)
+        bufs.append(d)
+        jobs.append((rb, d, m))
+        expected.append(S.oracle_msm(curve, b, inf, s[:m], 8))
+    jobs.append(jobs[0]); expected.append(expected[0])          # a key may repeat
+    got = gpu.msm_batch_dev(jobs)
+    assert len(got) == len(jobs)
+    assert gpu.msm_batch_timing(len(jobs) - 1)["window_bits"] > 0 and gpu.msm_batch_timing(3)["window_bits"] == 0   # job 3 is empty
+    for i, (g_xyz, e_xyz) in enumerate(zip(got, expected)):
+        assert affine_eq(gpu, curve, g_xyz, e_xyz), i
+    one_by_one = [rb.msm_dev(d, m) for rb, d, m in jobs]         # (projective triples differ run to run: list order
+    for a, b2 in zip(got, one_by_one):                           #  inside a bucket comes from atomics; SURVEY F7)
+        xa, ia = gpu.proj_to_affine(curve, a)
+        xb, ib = gpu.proj_to_affine(curve, b2)
+        assert ia == ib and (xa == xb).all()
+    for d in bufs:
+        d.free()
+    for rb, _, _ in keys:
+        rb.free()

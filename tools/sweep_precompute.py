@@ -43,6 +43,16 @@ def run(tag):
     print("%-10s c=%2d W=%2d  wall %8.2f ms  %6.2f M/s | sort %6.2f acc %7.2f heavy %5.2f (%d) reduce %6.2f fold %5.2f" % (
         tag, tm["window_bits"], tm["num_windows"], dt, n / dt / 1e3, tm["sort_ms"], tm["accumulate_ms"], tm["heavy_ms"],
         tm["heavy_buckets"], tm["reduce_ms"], tm["fold_ms"]), flush=True)
+    k = 6
+    gl.msm_batch_dev([(rb, ds, n)] * 2)
+    t0 = time.perf_counter()
+    outs = gl.msm_batch_dev([(rb, ds, n)] * k)
+    dtb = (time.perf_counter() - t0) * 1e3 / k
+    tms = [gl.msm_batch_timing(i) for i in range(k)]
+    ra = gl.proj_to_affine(curve, out)
+    same = all((lambda a: a[1] == ra[1] and bool((a[0] == ra[0]).all()))(gl.proj_to_affine(curve, o)) for o in outs)
+    print("           batch of %d pipelined: %8.2f ms per MSM  %6.2f M/s | acc %s | reduce %s | same result: %s" % (
+        k, dtb, n / dtb / 1e3, " ".join("%.1f" % t["accumulate_ms"] for t in tms), " ".join("%.1f" % t["reduce_ms"] for t in tms), same), flush=True)
     return gl.proj_to_affine(curve, out)
 
 
