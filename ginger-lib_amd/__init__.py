@@ -31,7 +31,7 @@ ABI_SYMBOLS = [
     "gh_init", "gh_shutdown", "gh_last_error", "gh_device_name",
     "gh_msm", "gh_bases_upload", "gh_bases_free", "gh_bases_len", "gh_bases_precompute", "gh_bases_precomputed_window",
     "gh_msm_resident", "gh_msm_resident_dev", "gh_msm_resident_dev_batch",
-    "gh_msm_set_window", "gh_msm_get_window", "gh_msm_last_timing", "gh_msm_batch_timing",
+    "gh_msm_set_window", "gh_msm_set_affine", "gh_msm_get_window", "gh_msm_last_timing", "gh_msm_batch_timing",
     "gh_domain_supported", "gh_fft", "gh_fft_dev", "gh_vec_mul_dev", "gh_vec_sub_dev", "gh_vec_scale_dev",
     "gh_vec_mul", "gh_vec_scale", "gh_fft_last_kernel_ms", "gh_witness_map", "gh_witness_map_dev",
     "gh_dev_alloc", "gh_dev_free", "gh_dev_upload", "gh_dev_download", "gh_dev_sync",
@@ -79,6 +79,7 @@ def load_library():
     lib.gh_msm_resident_dev.argtypes = [vp, vp, sz, vp]
     lib.gh_msm_resident_dev_batch.argtypes = [vp, vp, vp, ci, vp]
     lib.gh_msm_set_window.argtypes = [ci]
+    lib.gh_msm_set_affine.argtypes = [ci]
     lib.gh_msm_get_window.argtypes = [ci, sz]
     lib.gh_msm_last_timing.argtypes = [ctypes.POINTER(MsmTiming)]
     lib.gh_msm_batch_timing.argtypes = [ci, ctypes.POINTER(MsmTiming)]
@@ -239,6 +240,10 @@ class VariableBaseMSM:
 
 def msm_set_window(c):
     _check(load_library().gh_msm_set_window(int(c)))
+
+
+def msm_set_affine(on):
+    _check(load_library().gh_msm_set_affine(1 if on else 0))
 
 
 def msm_last_timing():

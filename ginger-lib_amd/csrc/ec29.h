@@ -15,11 +15,13 @@ namespace gh {
 // F  = field policy with the Fp product inlined (G1 accumulation inner loop);
 // FC = the same field with out-of-line products, used by the proj_*_call instances below.
 struct Mnt4G1 {  // y^2 = x^3 + 2x + b over p4       (curves/mnt4753/g1.rs:19-50)
+    typedef P4 PF;
     typedef F1<P4, true> F;
     typedef F1<P4, false> FC;
     static GH_HD F::T mul_by_a(const F::T& z) { return fp_dbl<P4>(z); }
 };
 struct Mnt6G1 {  // y^2 = x^3 + 11x + b over p6      (curves/mnt6753/g1.rs:19-52)
+    typedef P6 PF;
     typedef F1<P6, true> F;
     typedef F1<P6, false> FC;
     static GH_HD F::T mul_by_a(const F::T& z) { return fp_mul_small<P6, 11>(z); }

@@ -29,6 +29,7 @@ int ensure_init() {
     HIPCHK(hipSetDevice(dev));
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, dev));
+    g.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     snprintf(g_devname, sizeof g_devname, "%s, %d CUs, %s", prop.name, prop.multiProcessorCount, prop.gcnArchName);
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
         g_err = std::string("device is not gfx950: ") + prop.gcnArchName;
@@ -277,6 +278,11 @@ int gh_msm_set_window(int c) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (c < 0 || c > 24 || c == 1) { g_err = "window must be 0 (auto) or in [2, 24]"; return GH_E_BAD_ARG; }
     g.window_override = c;
+    return GH_OK;
+}
+int gh_msm_set_affine(int on) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g.affine_mode = on ? 1 : 0;
     return GH_OK;
 }
 int gh_msm_get_window(gh_curve_t curve, size_t n) {

@@ -438,6 +438,58 @@ struct MsmJob {
         if (slots > total)   // padding slots of the last pseudo-window: infinity (Z = 0)
             HIPCHK(hipMemsetAsync((void*)(buckets + total), 0, (slots - total) * sizeof(Proj<C>), st));
         HIPCHK(hipEventRecord(g.pev[slot][2], st));
+        // G1 on a shift table: bucket sums in affine coordinates (msm_kernels.h 4c), the projective kernel
+        // only for the chunks of heavy buckets and for the buckets the affine kernel flags.
+        // Opt-in (gh_msm_set_affine / GH_AFFINE=1): correct and tested, but at 2^20 pairs it takes 27.6 ms against
+        // 22.6 ms for the projective kernel -- 20 % fewer VALU instructions, yet the VALU pipe is busy only 57 %
+        // of the time (projective: 82 %); see DESIGN.md section 4 for the counters.
+        static const bool affine_env = getenv("GH_AFFINE") != nullptr && atoi(getenv("GH_AFFINE")) != 0;
+        bool affine = false;
+        if constexpr (C::F::DEG == 1) affine = merged && (affine_env || g.affine_mode != 0);
+        if (affine) {
+            if constexpr (C::F::DEG == 1) {
+                const uint32_t n_entries = hplan[2];
+                uint32_t n_lanes = (uint32_t)g.num_cus * 512u;              // 2 blocks of 256 per CU
+                uint32_t T = (n_entries + n_lanes - 1) / n_lanes;
+                if (T < 64) T = 64;
+                if (T > 512) T = 512;
+                {   // small inputs: no more lanes (and private scratch) than there are slices
+                    const uint32_t items = (n_entries + T - 1) / T + 1;
+                    const uint32_t need = (items + 255u) / 256u * 256u;
+                    if (need < n_lanes) n_lanes = need;
+                }
+                const uint32_t aff_thr = heavy_thr < 256 ? heavy_thr : 256;
+                AffTreeArgs<C> a;
+                a.table = (const Aff<C>*)src_points; a.sorted = sorted; a.starts = starts; a.counts = counts;
+                a.total = (uint32_t)total; a.n_entries = n_entries; a.T = T; a.n_items = (n_entries + T - 1) / T;
+                if (a.n_items == 0) a.n_items = 1;
+                a.n_lanes = n_lanes; a.aff_thr = aff_thr; a.heavy_thr = heavy_thr; a.cap = T + aff_thr + 8;
+                uint32_t *flags, *flist, *fcount;
+                if ((rc = pool_get("aff_bufA", (size_t)n_lanes * a.cap * sizeof(Aff<C>), (void**)&a.bufA))) return rc;
+                if ((rc = pool_get("aff_bufB", (size_t)n_lanes * a.cap * sizeof(Aff<C>), (void**)&a.bufB))) return rc;
+                if ((rc = pool_get("aff_prefix", (size_t)n_lanes * (a.cap / 2 + 2) * sizeof(Fp), (void**)&a.prefix))) return rc;
+                if ((rc = pool_get("aff_desc", (size_t)n_lanes * (a.cap / 2 + 2) * sizeof(uint4), (void**)&a.desc))) return rc;
+                if ((rc = pool_get("aff_flags", total * 4, (void**)&flags))) return rc;
+                if ((rc = pool_get("aff_flist", total * 4, (void**)&flist))) return rc;
+                if ((rc = pool_get("aff_fcount", 16, (void**)&fcount))) return rc;
+                a.flags = flags; a.buckets = buckets;
+                HIPCHK(hipMemsetAsync(flags, 0, total * 4, st));
+                HIPCHK(hipMemsetAsync(fcount, 0, 16, st));
+                if (n_chunks > 0)   // chunks of the heavy buckets only (total := n_heavy leaves no whole-bucket task)
+                    hipLaunchKernelGGL((msm_accumulate_kernel<C, 2>), dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, st,
+                                       (const Aff<C>*)src_points, (const uint32_t*)sorted, (const uint32_t*)starts,
+                                       (const uint32_t*)counts, (const uint32_t*)order, n_heavy, (const Aff<C>*)salts, buckets,
+                                       (const uint32_t*)chunk_start, n_heavy, n_chunks, heavy_chunk, partials, (const uint32_t*)nullptr);
+                hipLaunchKernelGGL((msm_affine_tree_kernel<C>), dim3(n_lanes / 256), dim3(256), 0, st, a);
+                hipLaunchKernelGGL(msm_collect_flagged_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                                   (const uint32_t*)flags, (uint32_t)total, flist, fcount);
+                // flagged buckets (equal x in some addition, or longer than aff_thr): one projective task each
+                hipLaunchKernelGGL((msm_accumulate_kernel<C, 2>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                                   (const Aff<C>*)src_points, (const uint32_t*)sorted, (const uint32_t*)starts,
+                                   (const uint32_t*)counts, (const uint32_t*)flist, 0u, (const Aff<C>*)salts, buckets,
+                                   (const uint32_t*)chunk_start, 0u, 0u, heavy_chunk, partials, (const uint32_t*)fcount);
+            }
+        } else {
         {
             // one launch: the chunks of the heavy buckets first, then every other bucket, longest first
             const size_t tasks = (size_t)n_chunks + (total - n_heavy);
@@ -460,13 +512,14 @@ struct MsmJob {
                     hipLaunchKernelGGL((msm_accumulate_kernel<C, 2>), dim3((unsigned)((tasks + 255) / 256)), dim3(256), 0, st,
                                        (const Aff<C>*)src_points, (const uint32_t*)sorted, (const uint32_t*)starts,
                                        (const uint32_t*)counts, (const uint32_t*)order, (uint32_t)total, (const Aff<C>*)salts, buckets,
-                                       (const uint32_t*)chunk_start, n_heavy, n_chunks, heavy_chunk, partials);
+                                       (const uint32_t*)chunk_start, n_heavy, n_chunks, heavy_chunk, partials, (const uint32_t*)nullptr);
                 else
                     hipLaunchKernelGGL((msm_accumulate_kernel<C, 1>), dim3((unsigned)((tasks + 255) / 256)), dim3(256), 0, st,
                                        (const Aff<C>*)src_points, (const uint32_t*)sorted, (const uint32_t*)starts,
                                        (const uint32_t*)counts, (const uint32_t*)order, (uint32_t)total, (const Aff<C>*)salts, buckets,
-                                       (const uint32_t*)chunk_start, n_heavy, n_chunks, heavy_chunk, partials);
+                                       (const uint32_t*)chunk_start, n_heavy, n_chunks, heavy_chunk, partials, (const uint32_t*)nullptr);
             }
+        }
         }
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(g.pev[slot][3], st));

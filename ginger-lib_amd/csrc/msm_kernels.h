@@ -392,10 +392,12 @@ msm_accumulate_kernel(const Aff<C>* __restrict__ bases, const uint32_t* __restri
                       const uint32_t* __restrict__ order, uint32_t total,
                       const Aff<C>* __restrict__ salts, Proj<C>* __restrict__ buckets,
                       const uint32_t* __restrict__ chunk_start, uint32_t n_heavy, uint32_t n_chunks, uint32_t chunk,
-                      Proj<C>* __restrict__ partials) {
+                      Proj<C>* __restrict__ partials, const uint32_t* __restrict__ dyn_total) {
     typedef typename C::F F;
     // task list: [0, n_chunks) chunks of the heavy buckets (the longest tasks, scheduled first),
     //            then the buckets order[n_heavy ..] by descending size
+    // (dyn_total: the list length lives in device memory -- the fallback list of the affine path)
+    if (dyn_total != nullptr) total = *dyn_total;
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_chunks + (total - n_heavy)) return;
     uint32_t beg, cnt;
@@ -705,6 +707,195 @@ msm_accumulate_split_kernel(const Aff<C>* __restrict__ bases, const uint32_t* __
         st_fp(o + 1 * LANES + comp, ay);
         st_fp(o + 2 * LANES + comp, az);
     }
+}
+
+// ---------------------------------------------------------------- 4c. bucket sums in AFFINE coordinates
+// With one bucket set (shift table) a bucket sum is a sum of ~36 table points in any order.  In
+// affine coordinates an addition costs 1 inversion + 2 M + 1 S; Montgomery's trick turns the
+// inversions of G independent additions into ONE inversion + 3 (G - 1) M, and the safegcd inversion
+// (fp29.h fp_inv) costs about 40 M -- so an addition comes to ~6 M + 40/G against the 11 M of the
+// projective mixed addition.  Independent additions come from pairing: round r adds the points of a
+// bucket two by two (c -> ceil(c / 2) points), ~log2(c) rounds.
+//
+// One lane owns the whole buckets whose lists start inside its slice of T list entries (~8 buckets,
+// ~288 entries at 2^20 pairs) and runs every round privately: forward pass (denominators x2 - x1,
+// running products parked in its scratch), one inversion, backward pass (lambda, x3, y3 into the
+// other of two private point buffers).  No cross-lane step, no atomics.  288 GB of HBM pay for
+// the private scratch (~0.2 MB per resident lane).
+//
+// Not handled here, by design: x2 == x1 (P + P, P - P) -- the denominator is replaced by 1 so the
+// batch stays invertible, the bucket is flagged, and the flagged buckets are summed again by the
+// projective kernel above (detour through the salt point) after this launch; buckets longer than
+// aff_thr are flagged up front; buckets longer than heavy_thr are the chunked ones (left alone).
+template <class C> __device__ __forceinline__ Aff<C> ld_aff16(const Aff<C>* p) {   // 16-byte loads (records are 16-byte aligned)
+    static_assert(sizeof(Aff<C>) % 16 == 0, "Aff must be a multiple of 16 bytes");
+    Aff<C> r;
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    uint4* d = reinterpret_cast<uint4*>(&r);
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(Aff<C>) / 16); i++) d[i] = q[i];
+    return r;
+}
+template <class C> __device__ __forceinline__ void st_aff16(Aff<C>* p, const Aff<C>& v) {
+    uint4* q = reinterpret_cast<uint4*>(p);
+    const uint4* s = reinterpret_cast<const uint4*>(&v);
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(Aff<C>) / 16); i++) q[i] = s[i];
+}
+template <class C> struct AffTreeArgs {
+    const Aff<C>* table;
+    const uint32_t *sorted, *starts, *counts;
+    uint32_t total;              // bucket slots
+    uint32_t n_entries, T, n_items, n_lanes;
+    uint32_t aff_thr, heavy_thr, cap;
+    Aff<C>*bufA, *bufB;          // n_lanes x cap points each
+    Fp* prefix;                  // n_lanes x (cap / 2 + 2)
+    uint4* desc;                 // n_lanes x (cap / 2 + 2): (index of the pair's first input, output index, bucket, -)
+    uint32_t* flags;             // per bucket
+    Proj<C>* buckets;
+};
+
+static __device__ __forceinline__ uint32_t first_bucket_at(const uint32_t* starts, uint32_t total, uint32_t e) {
+    uint32_t lo = 0, hi = total;   // first b with starts[b] >= e  (starts is non-decreasing)
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (starts[mid] < e) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+
+template <class C>
+__global__ void __launch_bounds__(256, 2) msm_affine_tree_kernel(AffTreeArgs<C> a) {
+    typedef typename C::F F;
+    typedef typename F::T FT;
+    static_assert(F::DEG == 1, "affine tree kernel: prime-field curves");
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= a.n_lanes) return;
+    // Private scratch, interleaved by lane inside a wave: slot s of lane l sits at (s * 64 + l).  The lanes of
+    // a wave walk their slots nearly in step, so one wave-wide access stays within a few KB (one TLB
+    // fragment, shared cache lines) instead of 64 regions 90 KB apart.
+    const size_t wv = gid >> 6, ln = gid & 63u;
+    Aff<C>* const bufA = a.bufA + wv * a.cap * 64 + ln;
+    Aff<C>* const bufB = a.bufB + wv * a.cap * 64 + ln;
+    Fp* const pre = a.prefix + wv * (a.cap / 2 + 2) * 64 + ln;
+    uint4* const desc = a.desc + wv * (a.cap / 2 + 2) * 64 + ln;
+    auto count_of = [&](uint32_t b) -> uint32_t {   // entries this kernel sums for bucket b
+        const uint32_t c = a.counts[b];
+        return c > a.aff_thr ? 0u : c;
+    };
+    auto load_pt = [&](int r, const Aff<C>* in, uint32_t idx) -> Aff<C> {
+        if (r == 0) {
+            const uint32_t e = a.sorted[idx];
+            Aff<C> q = ld_aff16<C>(a.table + (e & 0x7FFFFFFFu));
+            if (e >> 31) q.y = F::neg(q.y);
+            return q;
+        }
+        return ld_aff16<C>(in + (size_t)idx * 64);
+    };
+    for (uint32_t item = gid; item < a.n_items; item += a.n_lanes) {
+        const uint32_t e0 = item * a.T;
+        const uint32_t b0 = first_bucket_at(a.starts, a.total, e0);
+        const uint32_t b1 = item + 1 == a.n_items ? a.total : first_bucket_at(a.starts, a.total, e0 + a.T);
+        uint32_t maxc = 0;
+        for (uint32_t b = b0; b < b1; b++) {
+            const uint32_t c = a.counts[b];
+            if (c > a.aff_thr && c <= a.heavy_thr) a.flags[b] = 1u;   // too long for the private buffers: projective fallback
+            const uint32_t ce = c > a.aff_thr ? 0u : c;
+            maxc = ce > maxc ? ce : maxc;
+        }
+        const int R = maxc <= 1 ? 0 : 32 - __clz((int)(maxc - 1));
+        for (int r = 0; r < R; r++) {
+            const Aff<C>* in = (r & 1) ? bufA : bufB;      // r = 0 reads the lists; r = 1 reads A, writes B; r = 2 reads B ...
+            Aff<C>* out = (r & 1) ? bufB : bufA;
+            // ---- descriptors (no field arithmetic): one (first input, output, bucket) triple per addition of
+            //      this round, bucket by bucket; odd leftovers are copied to their output slot
+            uint32_t np = 0, pos = 0, outpos = 0;
+            for (uint32_t b = b0; b < b1; b++) {
+                const uint32_t c0 = count_of(b);
+                const uint32_t cr = (c0 + (1u << r) - 1u) >> r;
+                const uint32_t base = r == 0 ? a.starts[b] : pos;
+                const uint32_t half = cr >> 1;
+                for (uint32_t j = 0; j < half; j++) desc[(size_t)(np + j) * 64] = make_uint4(base + 2 * j, outpos + j, b, 0u);
+                np += half;
+                if (cr & 1u) st_aff16<C>(out + (size_t)(outpos + half) * 64, load_pt(r, in, base + cr - 1));
+                pos += cr;
+                outpos += half + (cr & 1u);
+            }
+            if (np == 0) continue;
+            // source of element idx: round 0 -> table row of list entry idx (sign in bit 31), later -> in[idx]
+            auto src_of = [&](uint32_t idx) -> uint32_t { return r == 0 ? a.sorted[idx] : idx; };
+            auto x_at = [&](uint32_t src) -> FT {
+                const Aff<C>* p = r == 0 ? a.table + (src & 0x7FFFFFFFu) : in + (size_t)src * 64;
+                return ld_fp(reinterpret_cast<const Fp*>(p));
+            };
+            auto pt_at = [&](uint32_t src) -> Aff<C> {
+                if (r == 0) {
+                    Aff<C> q = ld_aff16<C>(a.table + (src & 0x7FFFFFFFu));
+                    if (src >> 31) q.y = F::neg(q.y);
+                    return q;
+                }
+                return ld_aff16<C>(in + (size_t)src * 64);
+            };
+            // ---- forward: denominators x2 - x1 and their running products (sources of the next pair are
+            //      fetched one iteration ahead: desc -> list entry -> table row is a chain of dependent loads)
+            FT acc = F::one();
+            {
+                uint4 de = desc[0];
+                uint32_t s1 = src_of(de.x), s2 = src_of(de.x + 1);
+                for (uint32_t k = 0; k < np; k++) {
+                    const uint32_t bk = de.z;
+                    const FT x1 = x_at(s1), x2 = x_at(s2);
+                    if (k + 1 < np) { de = desc[(size_t)(k + 1) * 64]; s1 = src_of(de.x); s2 = src_of(de.x + 1); }
+                    FT d = F::sub(x2, x1);
+                    if (F::is_zero(d)) { a.flags[bk] = 1u; d = F::one(); }
+                    acc = F::mul(acc, d);
+                    st_fp(pre + (size_t)k * 64, acc);
+                }
+            }
+            // ---- one inversion for all additions of this round
+            FT inv = fp_inv<typename C::PF>(acc);
+            // ---- backward: 1 / (x2 - x1) per pair, lambda, the sum
+            {
+                uint4 de = desc[(size_t)(np - 1) * 64];
+                uint32_t s1 = src_of(de.x), s2 = src_of(de.x + 1);
+                for (uint32_t k = np; k-- > 0;) {
+                    const uint32_t oidx = de.y;
+                    const Aff<C> p1 = pt_at(s1), p2 = pt_at(s2);
+                    if (k > 0) { de = desc[(size_t)(k - 1) * 64]; s1 = src_of(de.x); s2 = src_of(de.x + 1); }
+                    FT d = F::sub(p2.x, p1.x);
+                    if (F::is_zero(d)) d = F::one();
+                    FT dinv = inv;
+                    if (k > 0) dinv = F::mul(inv, ld_fp(pre + (size_t)(k - 1) * 64));
+                    inv = F::mul(inv, d);
+                    const FT lam = F::mul(F::sub(p2.y, p1.y), dinv);
+                    Aff<C> s3;
+                    s3.x = F::sub(F::sub(F::sqr(lam), p1.x), p2.x);
+                    s3.y = F::sub(F::mul(lam, F::sub(p1.x, s3.x)), p1.y);
+                    st_aff16<C>(out + (size_t)oidx * 64, s3);
+                }
+            }
+        }
+        // ---- results: one point per non-empty bucket, in bucket order, in the last round's output
+        const Aff<C>* fin = R == 0 ? nullptr : (((R - 1) & 1) ? bufB : bufA);
+        uint32_t pos = 0;
+        for (uint32_t b = b0; b < b1; b++) {
+            const uint32_t c = a.counts[b];
+            if (c > a.aff_thr) continue;                    // chunked (heavy) or flagged for the fallback
+            Proj<C> o;
+            if (c == 0) {
+                o = proj_zero<C>();
+            } else {
+                const Aff<C> q = R == 0 ? load_pt(0, nullptr, a.starts[b]) : ld_aff16<C>(fin + (size_t)pos * 64);
+                o.x = q.x; o.y = q.y; o.z = F::one();
+                pos++;
+            }
+            st_proj<C>(a.buckets + b, o);
+        }
+    }
+}
+
+// flagged buckets -> list for the projective kernel (dyn_total = n[0])
+static __global__ void __launch_bounds__(256)
+msm_collect_flagged_kernel(const uint32_t* __restrict__ flags, uint32_t total, uint32_t* __restrict__ list, uint32_t* __restrict__ n) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < total && flags[g] != 0) list[atomicAdd(n, 1u)] = g;
 }
 
 // wave-level sum of one projective point per lane through LDS; result valid in lane 0.

@@ -30,6 +30,7 @@ struct DevBuf {
 struct Ctx {
     bool ready = false;
     int device = 0;
+    int num_cus = 256;
     hipStream_t stream = nullptr;       // transforms, bucket sort
     hipStream_t stream_acc = nullptr;   // MSM accumulation (lowest priority: the filler of the pipeline)
     hipStream_t stream_red = nullptr;   // MSM bucket reduction (highest priority: short latency chains)
@@ -38,6 +39,7 @@ struct Ctx {
     std::map<int, Domain> domains[2];
     std::map<std::string, DevBuf> pool;
     int window_override = 0;
+    int affine_mode = 0;        // 1: G1 bucket sums on a shift table in affine coordinates (msm_kernels.h 4c)
     gh_msm_timing_t last_msm{};
     std::vector<gh_msm_timing_t> batch_tm;   // per-MSM timings of the last batch call
     float last_fft_ms = 0;

@@ -120,6 +120,11 @@ int gh_msm_resident_dev_batch(const gh_bases_t* handles, const void* const* d_sc
 /* Window size override for sweeps (0 = automatic).  Affects subsequent MSM calls. */
 int gh_msm_set_window(int c);
 int gh_msm_get_window(gh_curve_t curve, size_t n);
+/* Experimental (default off): on a G1 key with a shift table, sum the buckets in AFFINE coordinates --
+ * pairwise rounds, one safegcd inversion per lane and round via Montgomery's trick (~6 field products
+ * per addition instead of 11); additions with equal x and over-long buckets fall back to the projective
+ * kernel.  Same results; currently slower than the projective kernel.        */
+int gh_msm_set_affine(int on);
 
 /* Time spent by the last MSM call in its phases, milliseconds (device phases by HIP events on the
  * library stream, host fold by a host clock).  Any pointer may be NULL. */

@@ -22,6 +22,8 @@ template <class P> static void fp_op(int op, const uint32_t* a, const uint32_t* 
         case 9: r = fp_mul_small<P, 13>(x); break;
         case 10: r = fp_mul_small<P, 26>(x); break;
         case 11: r = fp_mul_small<P, 121>(x); break;
+        case 12: r = fp_inv<P>(x); break;
+        case 13: r = fp_inv_plain<P>(x); break;
         default: r = fp_zero();
     }
     fp_pack(out, r);

@@ -60,6 +60,25 @@ def test_field_ops(shim, fid, F):
         assert toint(out) == ((a * b + c * d) * RIinv) % p, it
 
 
+@pytest.mark.parametrize("fid,F", [(4, pyref.P4), (6, pyref.P6)])
+def test_field_inverse_safegcd(shim, fid, F):
+    """fp_inv / fp_inv_plain (Bernstein-Yang divsteps, 61 batches of 29) against Python's pow(x, -1, p):
+    random values, small and large ones, powers of two, and 0 -> 0 (fp_768.rs:551-554 returns None there)."""
+    p = F.p
+    RI = pow(2, 754, p)
+    rng = pyref.Rng(1234 + fid)
+    vals = [0, 1, 2, 3, p - 1, p - 2, (p - 1) // 2, (p + 1) // 2, 1 << 752, (1 << 752) - 1, 17, RI, pow(RI, -1, p)]
+    vals += [1 << k for k in range(0, 752, 37)] + [p - (1 << k) for k in range(1, 752, 41)]
+    vals += [rng.field_elem(p) for _ in range(1500)] + [rng.next_u64() + 1 for _ in range(50)]
+    out = (U * 24)()
+    for x in vals:
+        shim.t_fp_op(fid, 13, words(x), words(0), out)
+        assert toint(out) == (pow(x, -1, p) if x else 0), hex(x)
+        shim.t_fp_op(fid, 12, words(x), words(0), out)          # Montgomery in / out: (a R) -> a^-1 R
+        a = x * pow(RI, -1, p) % p
+        assert toint(out) == (pow(a, -1, p) * RI % p if x else 0), hex(x)
+
+
 @pytest.mark.parametrize("cid,name", list(enumerate(("mnt4753_g1", "mnt4753_g2", "mnt6753_g1", "mnt6753_g2"))))
 def test_curve_ops(shim, cid, name):
     C = pyref.CURVES[name]

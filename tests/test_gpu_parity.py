@@ -391,3 +391,40 @@ def test_msm_batch_pipelined(gpu):
         d.free()
     for rb, _, _ in keys:
         rb.free()
+
+
+@pytest.mark.parametrize("curve,n,windows", [("mnt4753_g1", 3000, (0, 9, 13)), ("mnt6753_g1", 700, (0, 12))])
+def test_msm_affine_bucket_sums_vs_oracle(gpu, curve, n, windows):
+    """gh_msm_set_affine(1): bucket sums in affine coordinates (pairwise rounds, batched safegcd inversion).
+    Duplicate and opposite bases in one bucket (equal x -> flagged -> projective fallback), buckets of every
+    length incl. longer than the private buffers (c = 9: hundreds of entries per bucket -> fallback / chunks),
+    zero / one / r - 1 scalars, an infinity base; same affine result as the oracle and as the projective path."""
+    C = pyref.CURVES[curve]
+    r = C.order
+    rng = pyref.Rng(777 + n)
+    pool = S.chain_points(C, 48, rng)
+    pts = [pool[(i * 5) % 48] for i in range(n)]
+    scal = [rng.field_elem(r) for _ in range(n)]
+    scal[:6] = [0, 1, r - 1, 2, (r - 1) // 2, (r + 1) // 2]
+    for i in range(10, 200, 7):            # equal pairs (P + P inside a bucket) and opposite pairs (P - P)
+        pts[i + 1] = pts[i]; scal[i + 1] = scal[i]
+        pts[i + 3] = C.neg(pts[i + 2]); scal[i + 3] = scal[i + 2]
+    for i in range(300, 600):              # many equal small scalars: long buckets of window 0
+        scal[i] = 3
+    pts[7] = None
+    b, inf = S.bases_array(C, pts)
+    s = S.scalar_array(scal)
+    exp = S.oracle_msm(curve, b, inf, s, 16)
+    rb = gpu.ResidentBases(curve, b, inf)
+    try:
+        for c in windows:
+            rb.precompute(c)
+            gpu.msm_set_affine(1)
+            got = rb.msm(s)
+            assert affine_eq(gpu, curve, got, exp), (curve, c, "affine")
+            assert affine_eq(gpu, curve, rb.msm(s[:n // 2]), S.oracle_msm(curve, b, inf, s[:n // 2], 16)), (curve, c, "short")
+            gpu.msm_set_affine(0)
+            assert affine_eq(gpu, curve, rb.msm(s), exp), (curve, c, "projective")
+    finally:
+        gpu.msm_set_affine(0)
+        rb.free()

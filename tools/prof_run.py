@@ -25,6 +25,8 @@ if what == "msm":
     s = rng.integers(0, 1 << 64, size=(n, 12), dtype=np.uint64)
     s[:, 11] &= np.uint64((1 << 40) - 1)
     rb = gl.ResidentBases("mnt4753_g1", bases)
+    if len(sys.argv) > 4 and sys.argv[4] == "table":
+        print("shift table window", rb.precompute(0), flush=True)
     ds = gl.DeviceBuffer(n * 96).upload(s)
     for r in range(reps):
         t0 = time.time(); rb.msm_dev(ds, n)
