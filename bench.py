@@ -172,10 +172,12 @@ def main():
     traffic_acc = traffic_ntt = None
     try:
         tr = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-        if args.log_n == 20:
-            traffic_acc = tr["msm_accumulate_kernel"]["fetch_bytes_per_launch"] + tr["msm_accumulate_kernel"]["write_bytes_per_launch"]
+        ent = tr["msm_accumulate_kernel"] if tm_last["window_bits"] == tr["msm_accumulate_kernel"]["window_bits"] else \
+            tr["msm_accumulate_kernel_per_window_path"]
+        if args.log_n == 20 and ent["window_bits"] == tm_last["window_bits"]:
+            traffic_acc = ent["fetch_bytes_per_launch"] + ent["write_bytes_per_launch"]
         if args.ntt_log_n == 24:
-            traffic_ntt = 3 * (tr["ntt_pass_kernel"]["fetch_bytes_per_launch"] + tr["ntt_pass_kernel"]["write_bytes_per_launch"])
+            traffic_ntt = tr["ntt_pass_kernel"]["fetch_bytes_per_transform"] + tr["ntt_pass_kernel"]["write_bytes_per_transform"]
     except Exception:
         pass
 
