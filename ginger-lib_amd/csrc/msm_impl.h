@@ -193,12 +193,12 @@ Proj<HC> fold_terms(FoldTerm<HC>* t, int nt) {   // sum pt * 2^ex
 }
 
 template <class HC>
-Proj<HC> fold_generic(const std::vector<Proj<HC>>& hw, int W, int c, int u, int top_unsigned) {
+Proj<HC> fold_generic(const std::vector<Proj<HC>>& hw, int W, int c, int u, int sw, int top_unsigned) {
     auto PT = [&](int which, int w, int k) { return &hw[(size_t)(which * W + w) * 3 + k]; };
     auto window_terms = [&](int w, FoldTerm<HC>* t) {
-        t[0] = FoldTerm<HC>{u + 6, PT(0, w, 1)};   // PW
+        t[0] = FoldTerm<HC>{u + sw, PT(0, w, 1)};  // PW   (sw = log2 of the items per wave: 6, or 5 / 4 for G2)
         t[1] = FoldTerm<HC>{u, PT(0, w, 2)};       // PS
-        t[2] = FoldTerm<HC>{6, PT(1, w, 0)};       // PA
+        t[2] = FoldTerm<HC>{sw, PT(1, w, 0)};      // PA
         t[3] = FoldTerm<HC>{0, PT(2, w, 0)};       // PB
     };
     Proj<HC> acc = proj_zero<HC>();
@@ -223,17 +223,17 @@ Proj<HC> fold_generic(const std::vector<Proj<HC>>& hw, int W, int c, int u, int 
 }
 
 template <class C>
-void fold_windows(const std::vector<Proj<C>>& hw, int W, int c, int u, int top_unsigned, uint64_t* out_xyz) {
+void fold_windows(const std::vector<Proj<C>>& hw, int W, int c, int u, int sw, int top_unsigned, uint64_t* out_xyz) {
     typedef typename HostCurveOf<C>::type HC;
     if constexpr (HostCurveOf<C>::fast) {
         std::vector<Proj<HC>> h64(hw.size());
         for (size_t i = 0; i < hw.size(); i++) {   // internal -> ABI Montgomery limbs == host representation
             proj_to_abi_host<C>(reinterpret_cast<uint64_t*>(&h64[i]), hw[i]);
         }
-        Proj<HC> acc = fold_generic<HC>(h64, W, c, u, top_unsigned);
+        Proj<HC> acc = fold_generic<HC>(h64, W, c, u, sw, top_unsigned);
         memcpy(out_xyz, &acc, sizeof(acc));
     } else {
-        Proj<C> acc = fold_generic<C>(hw, W, c, u, top_unsigned);
+        Proj<C> acc = fold_generic<C>(hw, W, c, u, sw, top_unsigned);
         proj_to_abi_host<C>(out_xyz, acc);
     }
 }
@@ -243,7 +243,7 @@ void fold_windows(const std::vector<Proj<C>>& hw, int W, int c, int u, int top_u
 //   sum_s s B_s = sum_w' R_w' + Q sum_w' w' T_w'
 // with R_w' = PW 2^(u+6) + PS 2^u + PA 2^6 + PB as above and T_w' the plain sum of pseudo-window w'.
 template <class HC>
-Proj<HC> fold_merged_generic(const std::vector<Proj<HC>>& hw, int Wp, int q, int u) {
+Proj<HC> fold_merged_generic(const std::vector<Proj<HC>>& hw, int Wp, int q, int u, int sw) {
     auto PT = [&](int which, int w, int k) -> const Proj<HC>& { return hw[(size_t)(which * Wp + w) * 3 + k]; };
     Proj<HC> spw = proj_zero<HC>(), sps = proj_zero<HC>(), spa = proj_zero<HC>(), spb = proj_zero<HC>();
     Proj<HC> run = proj_zero<HC>(), st = proj_zero<HC>();
@@ -254,21 +254,21 @@ Proj<HC> fold_merged_generic(const std::vector<Proj<HC>>& hw, int Wp, int q, int
         spb = proj_add<HC>(spb, PT(2, w, 0));
         if (w >= 1) { run = proj_add<HC>(run, PT(0, w, 0)); st = proj_add<HC>(st, run); }   // sum_w' w' T_w'
     }
-    FoldTerm<HC> t[5] = {{u + 6, &spw}, {u, &sps}, {6, &spa}, {0, &spb}, {q, &st}};
+    FoldTerm<HC> t[5] = {{u + sw, &spw}, {u, &sps}, {sw, &spa}, {0, &spb}, {q, &st}};
     Proj<HC> acc = fold_terms<HC>(t, 5);
     if (proj_is_zero<HC>(acc)) acc = proj_zero<HC>();
     return acc;
 }
 template <class C>
-void fold_merged(const std::vector<Proj<C>>& hw, int Wp, int q, int u, uint64_t* out_xyz) {
+void fold_merged(const std::vector<Proj<C>>& hw, int Wp, int q, int u, int sw, uint64_t* out_xyz) {
     typedef typename HostCurveOf<C>::type HC;
     if constexpr (HostCurveOf<C>::fast) {
         std::vector<Proj<HC>> h64(hw.size());
         for (size_t i = 0; i < hw.size(); i++) proj_to_abi_host<C>(reinterpret_cast<uint64_t*>(&h64[i]), hw[i]);
-        Proj<HC> acc = fold_merged_generic<HC>(h64, Wp, q, u);
+        Proj<HC> acc = fold_merged_generic<HC>(h64, Wp, q, u, sw);
         memcpy(out_xyz, &acc, sizeof(acc));
     } else {
-        Proj<C> acc = fold_merged_generic<C>(hw, Wp, q, u);
+        Proj<C> acc = fold_merged_generic<C>(hw, Wp, q, u, sw);
         proj_to_abi_host<C>(out_xyz, acc);
     }
 }
@@ -285,6 +285,7 @@ struct MsmJob {
     int slot = 0;
     bool merged = false;
     int c = 0, W = 0, top_unsigned = 0, RW = 0, L1 = 0, L2 = 0;
+    int tpw = 64, sw = 6;           // items per wave of the reduction programs (G2 lane groups: 32 / 16)
     uint32_t nb = 0, Q = 0, win_stride = 0, segs_per_window = 0, heavy_thr = 0, heavy_chunk = 0;
     size_t total = 0, slots = 0, max_heavy = 0, max_chunks = 0;
     uint32_t n_heavy = 0, n_chunks = 0;
@@ -335,14 +336,17 @@ struct MsmJob {
         // then 2 L2 + 17): as long as the launch stays within one wave per SIMD (1024 on MI355X) a shorter
         // L1 only shortens the chain; beyond that the steps of co-resident waves add up again
         // (measured at 2^20 buckets: L1 = 16 -> 6.2 ms, 8 -> 6.8, 4 -> 8.2, 32 -> 7.9).
+        static const bool split_reduce_off = getenv("GH_NO_SPLIT_REDUCE") != nullptr;
+        tpw = 64;
+        if (C::F::DEG == 2 && !split_reduce_off) tpw = 32;     // lane pairs  (msm_kernels.h 5b)
+        if (C::F::DEG == 3 && !split_reduce_off) tpw = 16;     // lane triples, 48 lanes busy
+        sw = tpw == 64 ? 6 : (tpw == 32 ? 5 : 4);
         L1 = MSM_REDUCE_L;
-        // (Fq3 stays at 16: its out-of-line products make the steps scratch-bandwidth bound, and more,
-        //  shorter programs were measured slower: 62.8 ms vs 58.7 ms at 2^17 buckets)
-        while (C::F::DEG < 3 && L1 > 4 && (size_t)RW * ((Q + 32u * L1 - 1) / (32u * L1)) <= 1024) L1 >>= 1;
+        while (L1 > 4 && (size_t)RW * ((Q + (uint32_t)(tpw / 2) * L1 - 1) / ((uint32_t)(tpw / 2) * L1)) <= 1024) L1 >>= 1;
         if (env_L1 == 4 || env_L1 == 8 || env_L1 == 16 || env_L1 == 32) L1 = env_L1;
-        const uint32_t seg_slots = 64 * (uint32_t)L1;
+        const uint32_t seg_slots = (uint32_t)tpw * (uint32_t)L1;
         segs_per_window = (Q + seg_slots - 1) / seg_slots;
-        L2 = (int)((segs_per_window + 63) / 64);               // items per lane, level 2 (one wave per window)
+        L2 = (int)((segs_per_window + tpw - 1) / tpw);         // items per lane group, level 2 (one wave per window)
         if ((size_t)W * n >= ((size_t)1 << 31) || total >= ((size_t)1 << 31)) {
             g_err = "MSM too large for 31-bit list entries";
             return GH_E_UNSUPPORTED;
@@ -541,13 +545,28 @@ struct MsmJob {
         static const int env_wpb = getenv("GH_REDUCE_WPB") ? atoi(getenv("GH_REDUCE_WPB")) : 1;
         int wpb = env_wpb >= 1 && (size_t)env_wpb * lds_wave <= 65536 && env_wpb <= 4 ? env_wpb : 1;   // waves per block
         const unsigned nb1 = (unsigned)(RW * segs_per_window), nb2 = (unsigned)(3 * RW);
-        hipLaunchKernelGGL((msm_wave_reduce_kernel<C>), dim3((nb1 + wpb - 1) / wpb), dim3(64 * wpb), lds_wave * wpb, st,
-                           i0, none, none, nb1, 1u, segs_per_window, L1, (const Aff<C>*)salts, seg_out);
-        // level 2: one wave per window and per array: weighted program on runW, plain sums of A and Bv
         const uint32_t all = 0xFFFFFFFFu;
+        // level 2: one wave per window and per array: weighted program on runW, plain sums of A and Bv
         WaveReduceIn<C> r0{seg_out, 3, 0, segs_per_window, 0, all}, r1{seg_out, 3, 1, segs_per_window, 1, all}, r2{seg_out, 3, 2, segs_per_window, 1, all};
-        hipLaunchKernelGGL((msm_wave_reduce_kernel<C>), dim3((nb2 + wpb - 1) / wpb), dim3(64 * wpb), lds_wave * wpb, st,
-                           r0, r1, r2, (uint32_t)RW, 3u, 1u, L2, (const Aff<C>*)salts, win_out);
+        bool launched = false;
+        if constexpr (C::F::DEG >= 2) {
+            if (tpw != 64) {
+                typedef typename std::conditional<C::F::DEG == 2, F2S<P4, 13>, F3S<P6, 11>>::type FS;
+                constexpr int LANES = FS::LANES, TPW = C::F::DEG == 2 ? 32 : 16;
+                const size_t lds_split = 64 * sizeof(P3);
+                hipLaunchKernelGGL((msm_wave_reduce_split_kernel<C, FS, LANES, TPW>), dim3(nb1), dim3(64), lds_split, st,
+                                   i0, none, none, nb1, 1u, segs_per_window, L1, (const Aff<C>*)salts, seg_out);
+                hipLaunchKernelGGL((msm_wave_reduce_split_kernel<C, FS, LANES, TPW>), dim3(nb2), dim3(64), lds_split, st,
+                                   r0, r1, r2, (uint32_t)RW, 3u, 1u, L2, (const Aff<C>*)salts, win_out);
+                launched = true;
+            }
+        }
+        if (!launched) {
+            hipLaunchKernelGGL((msm_wave_reduce_kernel<C>), dim3((nb1 + wpb - 1) / wpb), dim3(64 * wpb), lds_wave * wpb, st,
+                               i0, none, none, nb1, 1u, segs_per_window, L1, (const Aff<C>*)salts, seg_out);
+            hipLaunchKernelGGL((msm_wave_reduce_kernel<C>), dim3((nb2 + wpb - 1) / wpb), dim3(64 * wpb), lds_wave * wpb, st,
+                               r0, r1, r2, (uint32_t)RW, 3u, 1u, L2, (const Aff<C>*)salts, win_out);
+        }
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(g.pev[slot][5], st));
         HIPCHK(hipMemcpyAsync(hw, win_out, (size_t)9 * RW * sizeof(Proj<C>), hipMemcpyDeviceToHost, st));
@@ -571,14 +590,14 @@ struct MsmJob {
         // Horner over windows, high to low (variable_base.rs:73-82), with the powers of two of R_w
         // merged into the c doublings between windows:
         //   acc*2^c + R_w = (((acc*2^(c-u-6) + PW)*2^6 + PS)*2^(u-6) + PA)*2^6 + PB        (c >= u + 6)
-        int u = 6;
-        while ((1 << (u - 6)) < L1) u++;
+        int u = sw;
+        while ((1 << (u - sw)) < L1) u++;
         if (merged) {
             int lq = 0;
             while ((1u << lq) < Q) lq++;            // RW > 1 only with Q = 2^q; for RW == 1 the term is empty
-            fold_merged<C>(hwv, RW, lq, u, out_xyz);
+            fold_merged<C>(hwv, RW, lq, u, sw, out_xyz);
         } else {
-            fold_windows<C>(hwv, W, c, u, top_unsigned, out_xyz);
+            fold_windows<C>(hwv, W, c, u, sw, top_unsigned, out_xyz);
         }
         auto t_end = std::chrono::steady_clock::now();
         HIPCHK(hipEventElapsedTime(&tm.sort_ms, g.pev[slot][0], g.pev[slot][1]));

@@ -610,8 +610,9 @@ template <class P, int NR> struct F3S {
 #ifndef GH_SPLIT_WAVES
 #define GH_SPLIT_WAVES 1   // measured on Fq2: 58.0 ms at 1 wave/SIMD (512 registers) vs 61.1 ms at 2 (1.5 KB of spills)
 #endif
+// (Fq3: the rolled per-lane products need fewer live registers; 2 waves / SIMD tried here)
 template <class C, class F, int LANES>
-__global__ void __launch_bounds__(256, GH_SPLIT_WAVES)
+__global__ void __launch_bounds__(256, LANES == 3 ? 2 : GH_SPLIT_WAVES)
 msm_accumulate_split_kernel(const Aff<C>* __restrict__ bases, const uint32_t* __restrict__ sorted,
                            const uint32_t* __restrict__ starts, const uint32_t* __restrict__ counts,
                            const uint32_t* __restrict__ order, uint32_t total,
@@ -1103,5 +1104,166 @@ msm_wave_reduce_kernel(WaveReduceIn<C> in0, WaveReduceIn<C> in1, WaveReduceIn<C>
         }
     }
 }
+
+// ---------------------------------------------------------------- 5b. bucket reduction for G2: lane groups
+// The same wave program over the split field policies of section 4b: a point of the program lives in a
+// lane pair (Fq2) or triple (Fq3), one coefficient per lane, so a wave carries TPW = 32 / 16 items (Fq3:
+// lanes 48..63 idle) and every addition runs on inlined Fp products in registers -- the tower version of
+// msm_wave_reduce_kernel has to call out-of-line products whose operands travel through scratch.
+// Item index = g + TPW * i (g = group, i = slot of the group), so  sum index * x = TPW * A + Bv.
+struct P3 { Fp x, y, z; };
+template <class FS> __device__ __forceinline__ P3 p3_zero() { return P3{fp_zero(), FS::one(), fp_zero()}; }
+template <class FS> __device__ __forceinline__ P3 p3_add_sel(const P3& p, const P3& q, bool& same) {
+    const bool pz = FS::is_zero(p.z), qz = FS::is_zero(q.z);
+    Fp y1z2 = FS::mul(p.y, q.z);
+    Fp x1z2 = FS::mul(p.x, q.z);
+    Fp z1z2 = FS::mul(p.z, q.z);
+    Fp u = FS::sub(FS::mul(p.z, q.y), y1z2);
+    Fp v = FS::sub(FS::mul(p.z, q.x), x1z2);
+    same = !pz && !qz && FS::is_zero(u) && FS::is_zero(v);
+    Fp uu = FS::sqr(u);
+    Fp vv = FS::sqr(v);
+    Fp vvv = FS::mul(v, vv);
+    Fp r = FS::mul(vv, x1z2);
+    Fp a = FS::sub(FS::sub(FS::mul(uu, z1z2), vvv), FS::dbl(r));
+    P3 o;
+    o.x = FS::mul(v, a);
+    o.y = FS::sub(FS::mul(FS::sub(r, a), u), FS::mul(vvv, y1z2));
+    o.z = FS::mul(vvv, z1z2);
+#pragma unroll
+    for (int k = 0; k < NL; k++) {
+        o.x.l[k] = pz ? q.x.l[k] : (qz ? p.x.l[k] : o.x.l[k]);
+        o.y.l[k] = pz ? q.y.l[k] : (qz ? p.y.l[k] : o.y.l[k]);
+        o.z.l[k] = pz ? q.z.l[k] : (qz ? p.z.l[k] : o.z.l[k]);
+    }
+    return o;
+}
+
+template <class C, class FS, int LANES, int TPW>
+__global__ void __launch_bounds__(64, 1)
+msm_wave_reduce_split_kernel(WaveReduceIn<C> in0, WaveReduceIn<C> in1, WaveReduceIn<C> in2, uint32_t blocks_per_input,
+                             uint32_t n_inputs, uint32_t segs_per_window, int L, const Aff<C>* __restrict__ salts,
+                             Proj<C>* __restrict__ out) {
+    constexpr int LT = TPW == 32 ? 5 : (TPW == 16 ? 4 : 6);
+    static_assert((1 << LT) == TPW && TPW * LANES <= 64, "groups per wave");
+    extern __shared__ uint32_t lds_raw[];
+    P3* sh = reinterpret_cast<P3*>(lds_raw);
+    const int lane = threadIdx.x & 63;
+    const bool live = lane < TPW * LANES;
+    const int g = live ? lane / LANES : TPW, comp = lane % LANES;
+    const uint32_t gb = blockIdx.x;
+    if (gb >= n_inputs * blocks_per_input) return;
+    const uint32_t which = gb / blocks_per_input, blk = gb % blocks_per_input;
+    const WaveReduceIn<C> in = which == 0 ? in0 : (which == 1 ? in1 : in2);
+    const uint32_t w = blk / segs_per_window, seg = blk % segs_per_window;
+    const uint32_t item0 = seg * (uint32_t)TPW * (uint32_t)L;
+    // coefficient `comp` of coordinate e of a projective / affine point in memory
+    auto ld_c = [&](const void* pt, int e) { return ld_fp(reinterpret_cast<const Fp*>(pt) + LANES * e + comp); };
+    auto st_c = [&](void* pt, int e, const Fp& v) { st_fp(reinterpret_cast<Fp*>(pt) + LANES * e + comp, v); };
+    auto st_p3 = [&](Proj<C>* pt, const P3& v) { st_c(pt, 0, v.x); st_c(pt, 1, v.y); st_c(pt, 2, v.z); };
+    Proj<C>* o = out + ((size_t)which * blocks_per_input + blk) * 3;
+    if ((size_t)w * in.count + item0 >= (size_t)in.valid) {   // segment of padding slots only
+        if (g == 0) { const P3 z = p3_zero<FS>(); st_p3(o, z); st_p3(o + 1, z); st_p3(o + 2, z); }
+        return;
+    }
+    const int NS1 = in.mode == 1 ? L : 2 * L - 1;
+    const int NST = in.mode == 1 ? L + LT : NS1 + 3 * LT;
+    P3 run = p3_zero<FS>(), wacc = p3_zero<FS>(), tmp = p3_zero<FS>();
+    int step = 0, det = 0, salt_id = 0;
+    bool mydet = false, mid_done = false;
+    auto sh_store = [&](const P3& v) {
+        uint2* d = reinterpret_cast<uint2*>(sh + lane);
+        const uint2* sv = reinterpret_cast<const uint2*>(&v);
+#pragma unroll
+        for (int k = 0; k < (int)(sizeof(P3) / 8); k++) d[k] = sv[k];
+    };
+    auto sh_load = [&](int src_lane) {
+        P3 v;
+        const uint2* sv = reinterpret_cast<const uint2*>(sh + src_lane);
+        uint2* d = reinterpret_cast<uint2*>(&v);
+#pragma unroll
+        for (int k = 0; k < (int)(sizeof(P3) / 8); k++) d[k] = sv[k];
+        return v;
+    };
+    while (step < NST) {
+        int kind, off = 0, i = 0;
+        if (step < NS1) {
+            if (in.mode == 1) { kind = 0; i = L - 1 - step; }
+            else { kind = (step & 1) ? 1 : 0; i = L - 1 - (step >> 1); }
+        } else if (in.mode == 1) { kind = 4; off = (TPW / 2) >> (step - NS1); }
+        else if (step < NS1 + LT) { kind = 2; off = (TPW / 2) >> (step - NS1); }
+        else if (step < NS1 + 2 * LT) { kind = 3; off = 1 << (step - NS1 - LT); }
+        else {
+            kind = 4; off = (TPW / 2) >> (step - NS1 - 2 * LT);
+            if (!mid_done) {   // between scan and the last tree: publish runW = S_0, drop group 0 from the tree
+                if (g == 0) { st_p3(o, run); run = p3_zero<FS>(); }
+                mid_done = true;
+            }
+        }
+        const bool exch = kind >= 2;
+        if (exch && det == 0) sh_store(kind == 2 ? wacc : run);
+        if (exch) GH_WAVE_SYNC();
+        bool active;
+        P3 q = p3_zero<FS>();
+        if (kind == 0) {
+            const uint32_t k = item0 + (uint32_t)g + (uint32_t)TPW * (uint32_t)i;
+            active = live && k < in.count;
+            if (active) {
+                const Proj<C>* pt = in.base + ((size_t)w * in.count + k) * in.stride + in.offset;
+                q.x = ld_c(pt, 0); q.y = ld_c(pt, 1); q.z = ld_c(pt, 2);
+            }
+        } else if (kind == 1) {
+            active = live;
+            q = run;
+        } else {
+            active = live && (kind == 3 ? g + off < TPW : g < off);
+            if (active) q = sh_load(lane + off * LANES);
+        }
+        if (exch) GH_WAVE_SYNC();
+        const bool to_wacc = kind == 1 || kind == 2;
+        P3 p = to_wacc ? wacc : run;
+        if (det > 0) {
+            active = mydet;
+            if (det >= 2) p = tmp;
+            if (det != 2) {
+                q.x = ld_c(salts + salt_id, 0);
+                q.y = ld_c(salts + salt_id, 1);
+                if (det == 3) q.y = FS::neg(q.y);
+                q.z = FS::one();
+            }
+        }
+        bool same;
+        P3 r = p3_add_sel<FS>(p, q, same);
+        same = same && active;
+        if (det == 0) {
+            const bool any_same = __any(same) != 0;
+            if (active && !same) { if (to_wacc) wacc = r; else run = r; }
+            if (any_same) {
+                mydet = same;
+                // salt with x != p.x / p.z (all lanes run the product: the group shuffles need their partners)
+                const bool s0_hits = FS::eq(FS::mul(ld_c(salts, 0), p.z), p.x);
+                if (same) salt_id = s0_hits ? 1 : 0;
+                det = 1;
+            } else {
+                step++;
+            }
+        } else {
+            if (mydet) {
+                if (det < 3) tmp = r;
+                else if (to_wacc) wacc = r; else run = r;
+            }
+            if (det == 3) { det = 0; mydet = false; step++; } else det++;
+        }
+    }
+    if (g == 0) {
+        if (in.mode == 1) {
+            st_p3(o, run);
+        } else {
+            st_p3(o + 1, wacc);
+            st_p3(o + 2, run);
+        }
+    }
+}
+
 
 }  // namespace gh
