@@ -35,7 +35,7 @@ ABI_SYMBOLS = [
     "gh_domain_supported", "gh_fft", "gh_fft_dev", "gh_vec_mul_dev", "gh_vec_sub_dev", "gh_vec_scale_dev",
     "gh_vec_mul", "gh_vec_scale", "gh_fft_last_kernel_ms", "gh_witness_map", "gh_witness_map_dev",
     "gh_dev_alloc", "gh_dev_free", "gh_dev_upload", "gh_dev_download", "gh_dev_sync",
-    "gh_proj_add", "gh_proj_to_affine",
+    "gh_proj_add", "gh_proj_mul", "gh_proj_neg", "gh_proj_to_affine",
 ]
 
 
@@ -99,6 +99,8 @@ def load_library():
     lib.gh_dev_upload.argtypes = [vp, vp, sz]
     lib.gh_dev_download.argtypes = [vp, vp, sz]
     lib.gh_proj_add.argtypes = [ci, vp, vp]
+    lib.gh_proj_mul.argtypes = [ci, vp, vp, vp]
+    lib.gh_proj_neg.argtypes = [ci, vp]
     lib.gh_proj_to_affine.argtypes = [ci, vp, vp, vp]
     _lib = lib
     return lib
@@ -263,6 +265,33 @@ def proj_add(curve, acc, p):
     p = _u64(p)
     _check(load_library().gh_proj_add(CURVES[curve], _ptr(acc), _ptr(p)))
     return acc
+
+
+def proj_mul(curve, xyz, scalar12):
+    """scalar * point for one projective point (host side): GroupProjective::mul_assign."""
+    xyz = _u64(xyz)
+    k = _u64(scalar12, 12)
+    out = np.zeros_like(xyz)
+    _check(load_library().gh_proj_mul(CURVES[curve], _ptr(xyz), _ptr(k), _ptr(out)))
+    return out
+
+
+def proj_neg(curve, xyz):
+    out = _u64(xyz).copy()
+    _check(load_library().gh_proj_neg(CURVES[curve], _ptr(out)))
+    return out
+
+
+_FIELD_ONE = {}
+
+
+def field_one(curve):
+    """Montgomery one of the curve's coordinate field (12*deg u64): the Y of the canonical zero (0, 1, 0)."""
+    if curve not in _FIELD_ONE:
+        deg = CURVE_DEG[curve]
+        z = proj_mul(curve, np.zeros(36 * deg, dtype=np.uint64), np.zeros(12, dtype=np.uint64))
+        _FIELD_ONE[curve] = z[12 * deg:24 * deg].copy()
+    return _FIELD_ONE[curve]
 
 
 def proj_to_affine(curve, xyz):

@@ -465,6 +465,20 @@ int gh_proj_add(gh_curve_t curve, uint64_t* acc_xyz, const uint64_t* p_xyz) {
     return ops->proj_add(acc_xyz, p_xyz);
 }
 
+int gh_proj_mul(gh_curve_t curve, const uint64_t* p_xyz, const uint64_t* scalar12, uint64_t* out_xyz) {
+    if (!p_xyz || !scalar12 || !out_xyz) { g_err = "null argument"; return GH_E_BAD_ARG; }
+    const MsmOps* ops = ops_of(curve);
+    if (!ops) return GH_E_BAD_ARG;
+    return ops->proj_mul(p_xyz, scalar12, out_xyz);
+}
+
+int gh_proj_neg(gh_curve_t curve, uint64_t* xyz) {
+    if (!xyz) { g_err = "null argument"; return GH_E_BAD_ARG; }
+    const MsmOps* ops = ops_of(curve);
+    if (!ops) return GH_E_BAD_ARG;
+    return ops->proj_neg(xyz);
+}
+
 int gh_proj_to_affine(gh_curve_t curve, const uint64_t* xyz, uint64_t* out_xy, uint8_t* is_infinity) {
     if (!xyz || !out_xy || !is_infinity) { g_err = "null argument"; return GH_E_BAD_ARG; }
     const MsmOps* ops = ops_of(curve);

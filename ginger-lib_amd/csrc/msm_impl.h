@@ -685,6 +685,34 @@ template <class C> int proj_add_host(uint64_t* acc_xyz, const uint64_t* p_xyz) {
     return GH_OK;
 }
 
+// out = k * p for one point (the prover's r * delta_g1, s * g_a, ... of prover.rs:278-330): double-and-add
+// from the top bit like GroupProjective::mul_assign (short_weierstrass_projective.rs:521-540), on the
+// 64-bit-limb host field.  Host side; ~1 ms.
+template <class C> int proj_mul_host(const uint64_t* p_xyz, const uint64_t* scalar12, uint64_t* out_xyz) {
+    typedef typename HostCurveOf<C>::type HC;
+    static_assert(HostCurveOf<C>::fast, "host curve on ABI limbs");
+    Proj<HC> p, res = proj_zero<HC>();
+    memcpy(&p, p_xyz, sizeof(p));
+    bool found_one = false;
+    for (int bit = 767; bit >= 0; bit--) {
+        const bool b = (scalar12[bit >> 6] >> (bit & 63)) & 1u;
+        if (found_one) res = proj_dbl<HC>(res);
+        if (b) { res = proj_add<HC>(res, p); found_one = true; }
+    }
+    if (proj_is_zero<HC>(res)) res = proj_zero<HC>();
+    memcpy(out_xyz, &res, sizeof(res));
+    return GH_OK;
+}
+
+template <class C> int proj_neg_host(uint64_t* xyz) {   // (X, Y, Z) -> (X, -Y, Z)   (swp.rs Neg)
+    typedef typename HostCurveOf<C>::type HC;
+    Proj<HC> p;
+    memcpy(&p, xyz, sizeof(p));
+    if (!proj_is_zero<HC>(p)) p.y = HC::F::neg(p.y);
+    memcpy(xyz, &p, sizeof(p));
+    return GH_OK;
+}
+
 template <class C> int to_affine_host(const uint64_t* xyz, uint64_t* out_xy, uint8_t* is_infinity) {
     typedef typename C::F F;
     Proj<C> p = proj_from_abi_host<C>(xyz);
@@ -707,7 +735,8 @@ template <class C> int to_affine_host(const uint64_t* xyz, uint64_t* out_xy, uin
     const MsmOps* NAME() {                                                                     \
         static const MsmOps ops = {&upload_bases<CURVE>, &msm_run<CURVE>, &msm_host<CURVE>,    \
                                    &proj_add_host<CURVE>, &to_affine_host<CURVE>,              \
-                                   &precompute_bases<CURVE>, &msm_batch<CURVE>};               \
+                                   &precompute_bases<CURVE>, &msm_batch<CURVE>,                \
+                                   &proj_mul_host<CURVE>, &proj_neg_host<CURVE>};                                     \
         return &ops;                                                                           \
     }                                                                                          \
     }

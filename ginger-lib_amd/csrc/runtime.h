@@ -83,6 +83,8 @@ struct MsmOps {
     int (*to_affine)(const uint64_t* xyz, uint64_t* out_xy, uint8_t* is_infinity);
     int (*precompute)(BasesBase* h, int window_bits);
     int (*batch)(BasesBase* const* hs, const void* const* d_scalars, const size_t* n_scalars, int count, uint64_t* out_xyz);
+    int (*proj_mul)(const uint64_t* p_xyz, const uint64_t* scalar12, uint64_t* out_xyz);
+    int (*proj_neg)(uint64_t* xyz);
 };
 const MsmOps* msm_ops_mnt4753_g1();
 const MsmOps* msm_ops_mnt4753_g2();

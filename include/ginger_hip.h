@@ -199,6 +199,12 @@ int gh_dev_sync(void);
 /* acc = acc + p for two projective points in the MSM result format (used to fold the per-GPU
  * partial sums after the all-gather: SURVEY.md section 8e).  Runs on the host; no device needed. */
 int gh_proj_add(gh_curve_t curve, uint64_t* acc_xyz, const uint64_t* p_xyz);
+/* out = scalar * p for ONE projective point (canonical 12-u64 scalar): the handful of single scalar
+ * multiplications next to the MSMs in create_proof (groth16/prover.rs:278, :296, :311, :325-327;
+ * GroupProjective::mul_assign, short_weierstrass_projective.rs:521-540).  Runs on the host.    */
+int gh_proj_mul(gh_curve_t curve, const uint64_t* p_xyz, const uint64_t* scalar12, uint64_t* out_xyz);
+/* xyz = -xyz (sub_assign in prover.rs:331 is add of the negation).  Host side. */
+int gh_proj_neg(gh_curve_t curve, uint64_t* xyz);
 /* x||y (Montgomery) and *is_infinity from a projective result: the reference's into_affine()
  * (short_weierstrass_projective.rs:663-678).  Runs on the host.                              */
 int gh_proj_to_affine(gh_curve_t curve, const uint64_t* xyz, uint64_t* out_xy, uint8_t* is_infinity);
