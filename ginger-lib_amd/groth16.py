@@ -42,9 +42,11 @@ class ResidentProvingKey:
         for rb in self.tails.values():
             rb.free()
 
-    def create_proof_msms(self, input_assignment, aux_assignment, h_input_assignment, h_aux_assignment, r, s):
+    def create_proof_msms(self, input_assignment, aux_assignment, h_input_assignment, h_aux_assignment, r, s, h_dev=None):
         """All arguments are canonical 12-u64 scalars (rows).  Returns (A, B, C) as (xy, is_infinity) pairs:
-        exactly Proof { a: g_a.into_affine(), b: g2_b.into_affine(), c: g_c.into_affine() } (prover.rs:340-344)."""
+        exactly Proof { a: g_a.into_affine(), b: g2_b.into_affine(), c: g_c.into_affine() } (prover.rs:340-344).
+        h_dev = (DeviceBuffer, rows): the coefficients of h already on the device as canonical scalars (the output
+        of gh_witness_map_dev after into_repr); h_input_assignment / h_aux_assignment are then taken from it."""
         gl, pk, ni = self.gl, self.pk, self.num_inputs
         g1, g2 = self.g1, self.g2
         msm = gl.VariableBaseMSM.multi_scalar_mul
@@ -52,8 +54,22 @@ class ResidentProvingKey:
         mul = gl.proj_mul
         inp = np.ascontiguousarray(input_assignment, dtype=np.uint64).reshape(-1, 12)
         aux = np.ascontiguousarray(aux_assignment, dtype=np.uint64).reshape(-1, 12)
-        h_inp = np.ascontiguousarray(h_input_assignment, dtype=np.uint64).reshape(-1, 12)
-        h_aux = np.ascontiguousarray(h_aux_assignment, dtype=np.uint64).reshape(-1, 12)
+        if h_dev is not None:
+            import ctypes
+            h_buf, h_rows = h_dev
+            head = np.empty(ni * 12, dtype=np.uint64)
+            gl._check(gl.load_library().gh_dev_download(gl._ptr(head), h_buf.ptr, head.nbytes))
+            h_inp = head.reshape(ni, 12)
+            n_haux = int(h_rows) - ni
+
+            class _View:                      # the tail of h on the device: h[num_inputs..]  (prover.rs:262-267)
+                ptr = ctypes.c_void_p(h_buf.ptr.value + ni * 96)
+            d_haux, own_haux = _View, False
+        else:
+            h_inp = np.ascontiguousarray(h_input_assignment, dtype=np.uint64).reshape(-1, 12)
+            h_aux = np.ascontiguousarray(h_aux_assignment, dtype=np.uint64).reshape(-1, 12)
+            n_haux = len(h_aux)
+            d_haux, own_haux = gl.DeviceBuffer(max(96, h_aux.nbytes)).upload(h_aux), True
         r = np.ascontiguousarray(r, dtype=np.uint64)
         s = np.ascontiguousarray(s, dtype=np.uint64)
 
@@ -66,14 +82,14 @@ class ResidentProvingKey:
 
         # the four large G1 MSMs as one pipelined batch; the G2 one on its own (a batch stays on one curve)
         d_aux = gl.DeviceBuffer(max(96, aux.nbytes)).upload(aux)
-        d_haux = gl.DeviceBuffer(max(96, h_aux.nbytes)).upload(h_aux)
         t = self.tails
         a_aux_acc, b1_aux_acc, h_aux_acc, l_aux_acc = gl.msm_batch_dev([
             (t["a_query"], d_aux, len(aux)), (t["b_g1_query"], d_aux, len(aux)),
-            (t["h_query"], d_haux, len(h_aux)), (t["l_query"], d_aux, len(aux))])
+            (t["h_query"], d_haux, n_haux), (t["l_query"], d_aux, len(aux))])
         b2_aux_acc = t["b_g2_query"].msm_dev(d_aux, len(aux))
         d_aux.free()
-        d_haux.free()
+        if own_haux:
+            d_haux.free()
         # Compute A  (prover.rs:273-284)
         a_inputs_acc = msm(g1, pk["a_query"][1:ni], inp)
         g_a = mul(g1, proj(g1, pk["delta_g1"]), r)
