@@ -608,7 +608,7 @@ template <class P, int NR> struct F3S {
 // Same task list and addition as msm_accumulate_kernel, LANES lanes per task (2: Fq2 pairs, 3: Fq3
 // triples; a wave carries 64 / LANES tasks, the remaining lane of a triple wave idles).
 #ifndef GH_SPLIT_WAVES
-#define GH_SPLIT_WAVES 1   // measured on Fq2: 58.0 ms at 1 wave/SIMD (512 registers) vs 61.1 ms at 2 (1.5 KB of spills)
+#define GH_SPLIT_WAVES 1   // measured on Fq2 (twice): 119 ms at 1 wave/SIMD (512 registers) vs 135 ms at 2 (1.5 KB of spills), 2^20 pairs
 #endif
 // (Fq3: the rolled per-lane products need fewer live registers; 2 waves / SIMD tried here)
 template <class C, class F, int LANES>
