@@ -502,10 +502,14 @@ msm_accumulate_kernel(const Aff<C>* __restrict__ bases, const uint32_t* __restri
 //   even lane: c0 = a0 b0 + NR a1 b1        odd lane: c1 = a1 b0 + a0 b1
 // with the partner's coefficients fetched by a lane swap (26 DPP moves per operand).
 // 22 Fp-product times per mixed addition and lane pair, against 31 on one lane -- but in registers.
-template <class P, int NR> struct F2S {
+// DUAL = true: one dual product with a single reduction per lane (2028 mads, 4 operands + 2 accumulators live:
+// 512 registers, 1 wave / SIMD); DUAL = false: two plain products per lane (2704 mads, the register footprint
+// of the G1 kernel: 256 registers, 2 waves / SIMD -- what the VALU needs to be kept busy).
+template <class P, int NR, bool DUAL = true> struct F2S {
     typedef Fp T;
     static constexpr int DEG = 1;   // per-lane footprint
     static constexpr int LANES = 2;
+    static constexpr int WAVES = DUAL ? 1 : 2;
     static __device__ __forceinline__ bool odd() { return (threadIdx.x & 1u) != 0; }
     static __device__ __forceinline__ T swap(const T& a) {
         T r;
@@ -528,8 +532,14 @@ template <class P, int NR> struct F2S {
     static __device__ __forceinline__ T mul(const T& a, const T& b) {
         const bool o = odd();
         const T ao = swap(a), bo = swap(b);
-        // one dual product per lane:  even: a0 b0 + (NR a1) b1      odd: a1 b0 + a0 b1
-        return fp_mul2<P>(a, sel(o, bo, b), sel(o, ao, fp_mul_small<P, NR>(ao)), sel(o, b, bo));
+        // per lane:  even: a0 b0 + (NR a1) b1      odd: a1 b0 + a0 b1
+        if constexpr (DUAL) {
+            return fp_mul2<P>(a, sel(o, bo, b), sel(o, ao, fp_mul_small<P, NR>(ao)), sel(o, b, bo));
+        } else {
+            const T t1 = fp_mul<P>(a, sel(o, bo, b));
+            const T t2 = fp_mul<P>(sel(o, ao, fp_mul_small<P, NR>(ao)), sel(o, b, bo));
+            return fp_add<P>(t1, t2);
+        }
     }
     static __device__ __forceinline__ T mul_sub_mul(const T& a, const T& b, const T& c, const T& d) { return sub(mul(a, b), mul(c, d)); }
     static __device__ __forceinline__ T sqr(const T& a) { return mul(a, a); }
@@ -550,6 +560,7 @@ template <class P, int NR> struct F3S {
     typedef Fp T;
     static constexpr int DEG = 1;
     static constexpr int LANES = 3;
+    static constexpr int WAVES = 2;
     static __device__ __forceinline__ int comp() { return (int)((threadIdx.x & 63u) % 3u); }
     static __device__ __forceinline__ T rot(const T& a, int by) {   // coefficient held by lane (comp + by) mod 3 of this triple
         const int lane = threadIdx.x & 63, j = lane % 3, src = lane - j + (j + by) % 3;
@@ -610,9 +621,8 @@ template <class P, int NR> struct F3S {
 #ifndef GH_SPLIT_WAVES
 #define GH_SPLIT_WAVES 1   // measured on Fq2 (twice): 119 ms at 1 wave/SIMD (512 registers) vs 135 ms at 2 (1.5 KB of spills), 2^20 pairs
 #endif
-// (Fq3: the rolled per-lane products need fewer live registers; 2 waves / SIMD tried here)
 template <class C, class F, int LANES>
-__global__ void __launch_bounds__(256, LANES == 3 ? 2 : GH_SPLIT_WAVES)
+__global__ void __launch_bounds__(256, F::WAVES)
 msm_accumulate_split_kernel(const Aff<C>* __restrict__ bases, const uint32_t* __restrict__ sorted,
                            const uint32_t* __restrict__ starts, const uint32_t* __restrict__ counts,
                            const uint32_t* __restrict__ order, uint32_t total,
