@@ -245,7 +245,7 @@ def msm_set_window(c):
 
 
 def msm_set_affine(on):
-    _check(load_library().gh_msm_set_affine(1 if on else 0))
+    _check(load_library().gh_msm_set_affine(int(on)))
 
 
 def msm_last_timing():

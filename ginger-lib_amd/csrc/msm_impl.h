@@ -453,6 +453,7 @@ struct MsmJob {
         // 22.6 ms for the projective kernel -- 20 % fewer VALU instructions, yet the VALU pipe is busy only 57 %
         // of the time (projective: 82 %); see DESIGN.md section 4 for the counters.
         static const bool affine_env = getenv("GH_AFFINE") != nullptr && atoi(getenv("GH_AFFINE")) != 0;
+        static const bool affine_env2 = getenv("GH_AFFINE") != nullptr && atoi(getenv("GH_AFFINE")) == 2;
         bool affine = false;
         if constexpr (C::F::DEG == 1) affine = merged && (affine_env || g.affine_mode != 0);
         if (affine) {
@@ -474,14 +475,21 @@ struct MsmJob {
                 if (a.n_items == 0) a.n_items = 1;
                 a.n_lanes = n_lanes; a.aff_thr = aff_thr; a.heavy_thr = heavy_thr; a.cap = T + aff_thr + 8;
                 uint32_t *flags, *flist, *fcount;
-                if ((rc = pool_get("aff_bufA", (size_t)n_lanes * a.cap * sizeof(Aff<C>), (void**)&a.bufA))) return rc;
-                if ((rc = pool_get("aff_bufB", (size_t)n_lanes * a.cap * sizeof(Aff<C>), (void**)&a.bufB))) return rc;
+                const bool pair_mode = g.affine_mode == 2 || affine_env2;     // 4d: no point buffers, running products only
+                if ((rc = pool_get("aff_bufA", pair_mode ? 256 : (size_t)n_lanes * a.cap * sizeof(Aff<C>), (void**)&a.bufA))) return rc;
+                if ((rc = pool_get("aff_bufB", pair_mode ? 256 : (size_t)n_lanes * a.cap * sizeof(Aff<C>), (void**)&a.bufB))) return rc;
                 if ((rc = pool_get("aff_prefix", (size_t)n_lanes * (a.cap / 2 + 2) * sizeof(Fp), (void**)&a.prefix))) return rc;
                 if ((rc = pool_get("aff_desc", (size_t)n_lanes * (a.cap / 2 + 2) * sizeof(uint4), (void**)&a.desc))) return rc;
                 if ((rc = pool_get("aff_flags", total * 4, (void**)&flags))) return rc;
                 if ((rc = pool_get("aff_flist", total * 4, (void**)&flist))) return rc;
                 if ((rc = pool_get("aff_fcount", 16, (void**)&fcount))) return rc;
-                a.flags = flags; a.buckets = buckets;
+                a.flags = flags; a.buckets = buckets; a.work = fcount + 1;
+                if (pair_mode) {   // 4d hands slices out dynamically: more, shorter slices than lanes
+                    static const int env_T = getenv("GH_PAIR_T") ? atoi(getenv("GH_PAIR_T")) : 0;
+                    a.T = env_T > 0 ? (uint32_t)env_T : (T > 128 ? T / 2 : T);
+                    a.n_items = (n_entries + a.T - 1) / a.T;
+                    if (a.n_items == 0) a.n_items = 1;
+                }
                 HIPCHK(hipMemsetAsync(flags, 0, total * 4, st));
                 HIPCHK(hipMemsetAsync(fcount, 0, 16, st));
                 if (n_chunks > 0)   // chunks of the heavy buckets only (total := n_heavy leaves no whole-bucket task)
@@ -489,7 +497,10 @@ struct MsmJob {
                                        (const Aff<C>*)src_points, (const uint32_t*)sorted, (const uint32_t*)starts,
                                        (const uint32_t*)counts, (const uint32_t*)order, n_heavy, (const Aff<C>*)salts, buckets,
                                        (const uint32_t*)chunk_start, n_heavy, n_chunks, heavy_chunk, partials, (const uint32_t*)nullptr);
-                hipLaunchKernelGGL((msm_affine_tree_kernel<C>), dim3(n_lanes / 256), dim3(256), 0, st, a);
+                if (g.affine_mode == 2 || affine_env2)
+                    hipLaunchKernelGGL((msm_pair_madd_kernel<C>), dim3(n_lanes / 256), dim3(256), 0, st, a);
+                else
+                    hipLaunchKernelGGL((msm_affine_tree_kernel<C>), dim3(n_lanes / 256), dim3(256), 0, st, a);
                 hipLaunchKernelGGL(msm_collect_flagged_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
                                    (const uint32_t*)flags, (uint32_t)total, flist, fcount);
                 // flagged buckets (equal x in some addition, or longer than aff_thr): one projective task each

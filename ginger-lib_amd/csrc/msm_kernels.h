@@ -763,6 +763,7 @@ template <class C> struct AffTreeArgs {
     Fp* prefix;                  // n_lanes x (cap / 2 + 2)
     uint4* desc;                 // n_lanes x (cap / 2 + 2): (index of the pair's first input, output index, bucket, -)
     uint32_t* flags;             // per bucket
+    uint32_t* work;              // 4d: next unclaimed slice
     Proj<C>* buckets;
 };
 
@@ -899,6 +900,135 @@ __global__ void __launch_bounds__(256, 2) msm_affine_tree_kernel(AffTreeArgs<C> 
             }
             st_proj<C>(a.buckets + b, o);
         }
+    }
+}
+
+// ---------------------------------------------------------------- 4d. pairs in affine, pairs into the bucket projectively
+// One affine round only, consumed on the fly: the list entries of a bucket are taken two by two, the pair sum
+// S = P + Q is formed in affine coordinates (its inversion shared by all pairs of the lane: forward pass of
+// running products over x2 - x1, ONE safegcd inversion, backward pass), and S goes straight into the bucket's
+// projective accumulator by a mixed addition.  Per two entries: 1 + 5 + 11 = 17 products instead of 22; no
+// intermediate point is ever written (scratch: the running products only, 52 B per entry), one inversion per
+// ~144 pairs.  Same ownership as 4c (a lane owns the buckets of a slice of T list entries), same flags:
+// equal x in a pair, the accumulator meeting its own value, buckets longer than aff_thr -> projective fallback.
+template <class C>
+__global__ void __launch_bounds__(256, 2) msm_pair_madd_kernel(AffTreeArgs<C> a) {
+    typedef typename C::F F;
+    typedef typename F::T FT;
+    static_assert(F::DEG == 1, "pair kernel: prime-field curves");
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= a.n_lanes) return;
+    const size_t wv = gid >> 6, ln = gid & 63u;
+    Fp* const pre = a.prefix + wv * (a.cap / 2 + 2) * 64 + ln;      // lane-interleaved, as in 4c
+    __shared__ uint32_t park[NL][256];
+    auto pt_of = [&](uint32_t e) -> Aff<C> {
+        Aff<C> q = ld_aff16<C>(a.table + (e & 0x7FFFFFFFu));
+        if (e >> 31) q.y = F::neg(q.y);
+        return q;
+    };
+    auto x_of = [&](uint32_t e) -> FT { return ld_fp(reinterpret_cast<const Fp*>(a.table + (e & 0x7FFFFFFFu))); };
+    // slices are handed out dynamically, 64 at a time per wave (a.work: device counter, zeroed by the host):
+    // waves that finish early take more
+    for (;;) {
+        uint32_t first = 0;
+        if (ln == 0) first = atomicAdd(a.work, 64u);
+        first = (uint32_t)__shfl((int)first, 0);
+        if (first >= a.n_items) break;
+        const uint32_t item = first + (uint32_t)ln;
+        if (item >= a.n_items) continue;
+        const uint32_t e0 = item * a.T;
+        const uint32_t b0 = first_bucket_at(a.starts, a.total, e0);
+        const uint32_t b1 = item + 1 == a.n_items ? a.total : first_bucket_at(a.starts, a.total, e0 + a.T);
+        // ---- forward: x2 - x1 of every pair, running products
+        FT acc = F::one();
+        uint32_t np = 0;
+        for (uint32_t b = b0; b < b1; b++) {
+            const uint32_t c = a.counts[b];
+            if (c > a.aff_thr) { if (c <= a.heavy_thr) a.flags[b] = 1u; continue; }
+            const uint32_t base = a.starts[b], half = c >> 1;
+            for (uint32_t j = 0; j < half; j++) {
+                FT d = F::sub(x_of(a.sorted[base + 2 * j + 1]), x_of(a.sorted[base + 2 * j]));
+                if (F::is_zero(d)) { a.flags[b] = 1u; d = F::one(); }
+                acc = F::mul(acc, d);
+                st_fp(pre + (size_t)np * 64, acc);
+                np++;
+            }
+        }
+        FT inv = F::one();
+        if (np > 0) inv = fp_inv<typename C::PF>(acc);
+        // ---- backward: buckets last to first, pairs last to first; pair sum in affine, then one mixed addition.
+        //      ONE flat loop over the lane's pairs with a bucket cursor: with a loop per bucket the 64 lanes of a wave
+        //      wait for the longest bucket at every bucket position (measured: 39 ms instead of 23 ms).
+        uint32_t k = np, b = b1, j = 0, base = 0;
+        bool open = false;                       // P holds the running sum of bucket b
+        Proj<C> P = proj_zero<C>();
+        auto step_bucket = [&]() {               // close bucket b, open the one below it
+            if (open) st_proj<C>(a.buckets + b, P);
+            b--;
+            const uint32_t c = a.counts[b];
+            open = c <= a.aff_thr;
+            j = 0;
+            if (!open) return;
+            base = a.starts[b];
+            j = c >> 1;
+            P = proj_zero<C>();
+            if (c & 1u) { const Aff<C> q = pt_of(a.sorted[base + c - 1]); P.x = q.x; P.y = q.y; P.z = F::one(); }
+        };
+        while (k > 0) {
+            while (j == 0) step_bucket();
+            j--;
+            k--;
+            const Aff<C> p1 = pt_of(a.sorted[base + 2 * j]), p2 = pt_of(a.sorted[base + 2 * j + 1]);
+            FT d = F::sub(p2.x, p1.x);
+            if (F::is_zero(d)) d = F::one();
+            FT dinv = inv;
+            if (k > 0) dinv = F::mul(inv, ld_fp(pre + (size_t)(k - 1) * 64));
+            inv = F::mul(inv, d);
+            const FT lam = F::mul(F::sub(p2.y, p1.y), dinv);
+            Aff<C> q;
+            q.x = F::sub(F::sub(F::sqr(lam), p1.x), p2.x);
+            q.y = F::sub(F::mul(lam, F::sub(p1.x, q.x)), p1.y);
+            if (proj_is_zero<C>(P)) {
+                P.x = q.x; P.y = q.y; P.z = F::one();
+            } else {   // madd-1998-cmo (swp.rs:497-517), operation order as in msm_accumulate_kernel
+                FT v = F::mul(q.x, P.z);
+                FT u = F::mul(q.y, P.z);
+                if (F::eq(u, P.y) && F::eq(v, P.x)) a.flags[b] = 1u;     // P == q: the fallback sums this bucket
+                u = F::sub(u, P.y);
+                v = F::sub(v, P.x);
+                {
+                    const uint32_t* yw = reinterpret_cast<const uint32_t*>(&P.y);
+#pragma unroll
+                    for (int w = 0; w < NL; w++) park[w][threadIdx.x] = yw[w];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                FT vv = F::sqr(v);
+                __builtin_amdgcn_sched_barrier(0);
+                FT r = F::mul(vv, P.x);
+                __builtin_amdgcn_sched_barrier(0);
+                FT vvv = F::mul(v, vv);
+                __builtin_amdgcn_sched_barrier(0);
+                FT uu = F::sqr(u);
+                __builtin_amdgcn_sched_barrier(0);
+                FT aa = F::sub(F::sub(F::mul(uu, P.z), vvv), F::dbl(r));
+                __builtin_amdgcn_sched_barrier(0);
+                P.x = F::mul(v, aa);
+                __builtin_amdgcn_sched_barrier(0);
+                FT rma = F::sub(r, aa);
+                __builtin_amdgcn_sched_barrier(0);
+                FT y1;
+                {
+                    uint32_t* yw = reinterpret_cast<uint32_t*>(&y1);
+#pragma unroll
+                    for (int w = 0; w < NL; w++) yw[w] = park[w][threadIdx.x];
+                }
+                P.y = F::sub(F::mul(u, rma), F::mul(vvv, y1));
+                __builtin_amdgcn_sched_barrier(0);
+                P.z = F::mul(vvv, P.z);
+            }
+        }
+        while (b > b0) step_bucket();            // the buckets below the last pair: singles and empties
+        if (open) st_proj<C>(a.buckets + b, P);
     }
 }
 

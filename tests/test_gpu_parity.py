@@ -419,10 +419,12 @@ def test_msm_affine_bucket_sums_vs_oracle(gpu, curve, n, windows):
     try:
         for c in windows:
             rb.precompute(c)
-            gpu.msm_set_affine(1)
-            got = rb.msm(s)
-            assert affine_eq(gpu, curve, got, exp), (curve, c, "affine")
-            assert affine_eq(gpu, curve, rb.msm(s[:n // 2]), S.oracle_msm(curve, b, inf, s[:n // 2], 16)), (curve, c, "short")
+            exp_short = S.oracle_msm(curve, b, inf, s[:n // 2], 16)
+            for mode in (1, 2):               # 1: pairwise rounds, all in affine (4c); 2: one affine round + mixed additions (4d)
+                gpu.msm_set_affine(mode)
+                got = rb.msm(s)
+                assert affine_eq(gpu, curve, got, exp), (curve, c, "affine mode", mode)
+                assert affine_eq(gpu, curve, rb.msm(s[:n // 2]), exp_short), (curve, c, "short", mode)
             gpu.msm_set_affine(0)
             assert affine_eq(gpu, curve, rb.msm(s), exp), (curve, c, "projective")
     finally:
