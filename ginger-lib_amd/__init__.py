@@ -29,7 +29,7 @@ FIELDS = {"mnt4753_fr": 0, "mnt6753_fr": 1}
 # every symbol include/ginger_hip.h declares (checked by load_library and by tests/test_abi.py)
 ABI_SYMBOLS = [
     "gh_init", "gh_shutdown", "gh_last_error", "gh_device_name",
-    "gh_msm", "gh_bases_upload", "gh_bases_free", "gh_bases_len", "gh_bases_precompute", "gh_bases_precomputed_window",
+    "gh_msm", "gh_bases_upload", "gh_bases_upload_wire", "gh_bases_free", "gh_bases_len", "gh_bases_precompute", "gh_bases_precomputed_window",
     "gh_msm_resident", "gh_msm_resident_dev", "gh_msm_resident_dev_batch",
     "gh_msm_set_window", "gh_msm_set_affine", "gh_msm_get_window", "gh_msm_last_timing", "gh_msm_batch_timing",
     "gh_domain_supported", "gh_fft", "gh_fft_dev", "gh_vec_mul_dev", "gh_vec_sub_dev", "gh_vec_scale_dev",
@@ -70,6 +70,7 @@ def load_library():
     lib.gh_init.argtypes = [vp, ci]
     lib.gh_msm.argtypes = [ci, vp, vp, sz, vp, sz, vp]
     lib.gh_bases_upload.argtypes = [ci, vp, vp, sz, ctypes.POINTER(vp)]
+    lib.gh_bases_upload_wire.argtypes = [ci, vp, sz, ctypes.POINTER(vp)]
     lib.gh_bases_free.argtypes = [vp]
     lib.gh_bases_len.argtypes = [vp]
     lib.gh_bases_len.restype = sz
@@ -181,6 +182,20 @@ class ResidentBases:
         _check(load_library().gh_bases_upload(CURVES[curve], _ptr(bases), _ptr(inf) if inf is not None else None, n,
                                                ctypes.byref(self.handle)))
         self.n = n
+
+    @classmethod
+    def from_wire(cls, curve, data):
+        """data: bytes of n serialised affine points (GroupAffine::write: x || y || infinity byte, canonical LE)."""
+        buf = np.frombuffer(bytes(data), dtype=np.uint8)
+        rec = 192 * CURVE_DEG[curve] + 1
+        if buf.size % rec:
+            raise ValueError("wire data is not a multiple of %d bytes" % rec)
+        self = cls.__new__(cls)
+        self.curve = curve
+        self.n = buf.size // rec
+        self.handle = ctypes.c_void_p()
+        _check(load_library().gh_bases_upload_wire(CURVES[curve], _ptr(buf), self.n, ctypes.byref(self.handle)))
+        return self
 
     def precompute(self, window_bits=0):
         """Build the per-key shift table (gh_bases_precompute); returns the window size used."""

@@ -27,11 +27,13 @@ struct Mnt6G1 {  // y^2 = x^3 + 11x + b over p6      (curves/mnt6753/g1.rs:19-52
     static GH_HD F::T mul_by_a(const F::T& z) { return fp_mul_small<P6, 11>(z); }
 };
 struct Mnt4G2 {  // twist over Fq2, a' = (26, 0)     (curves/mnt4753/g2.rs:57-75, mul_by_a :113-118)
+    typedef P4 PF;
     typedef F2<P4, 13, false> F;   // inlining the 31 Fp products of an Fq2 mixed addition was measured
     typedef F2<P4, 13, false> FC;  // SLOWER (3.7 KB of spills per lane) than out-of-line products
     static GH_HD F::T mul_by_a(const F::T& z) { return F::T{fp_mul_small<P4, 26>(z.c0), fp_mul_small<P4, 26>(z.c1)}; }
 };
 struct Mnt6G2 {  // twist over Fq3, a' = (0, 0, 11)  (curves/mnt6753/g2.rs:71-100, mul_by_a :149-155)
+    typedef P6 PF;
     typedef F3<P6, 11, false> F;
     typedef F3<P6, 11, false> FC;
     static GH_HD F::T mul_by_a(const F::T& z) {

@@ -178,7 +178,41 @@ int gh_bases_upload(gh_curve_t curve, const uint64_t* bases, const uint8_t* infi
     int rc = ensure_init();
     if (rc) return rc;
     BasesBase* h = nullptr;
-    rc = ops->upload(bases, infinity, n_bases, &h);
+    rc = ops->upload(bases, infinity, n_bases, 0, &h);
+    if (rc) return rc;
+    *out_handle = reinterpret_cast<gh_bases_t>(h);
+    return GH_OK;
+}
+
+// GroupAffine::write (short_weierstrass_projective.rs:185-192): x || y || infinity byte, every base-field
+// coefficient as 96 little-endian bytes of its CANONICAL integer (Fp768::write = into_repr().write, fp_768.rs:784-789).
+int gh_bases_upload_wire(gh_curve_t curve, const uint8_t* bytes, size_t n_points, gh_bases_t* out_handle) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!out_handle || (n_points && !bytes)) { g_err = "null argument"; return GH_E_BAD_ARG; }
+    const MsmOps* ops = ops_of(curve);
+    if (!ops) return GH_E_BAD_ARG;
+    int rc = ensure_init();
+    if (rc) return rc;
+    const int deg = curve == GH_MNT4753_G2 ? 2 : (curve == GH_MNT6753_G2 ? 3 : 1);
+    static const uint64_t p4[12] = GH_P4_P_64, p6[12] = GH_P6_P_64;
+    const uint64_t* mod = (curve == GH_MNT4753_G1 || curve == GH_MNT4753_G2) ? p4 : p6;
+    const size_t rec = (size_t)192 * deg + 1, words = (size_t)24 * deg;
+    std::vector<uint64_t> xy(n_points * words);
+    std::vector<uint8_t> inf(n_points);
+    for (size_t i = 0; i < n_points; i++) {
+        const uint8_t* r = bytes + i * rec;
+        memcpy(&xy[i * words], r, 192 * (size_t)deg);
+        if (r[rec - 1] > 1) { g_err = "wire format: infinity flag is not 0 / 1 (bool::read fails)"; return GH_E_BAD_ARG; }
+        inf[i] = r[rec - 1];
+        for (size_t e = 0; e < 2 * (size_t)deg; e++) {   // FromBytes rejects values >= p (fp_768.rs:791-805)
+            const uint64_t* v = &xy[i * words + 12 * e];
+            bool lt = false;
+            for (int k = 11; k >= 0; k--) { if (v[k] != mod[k]) { lt = v[k] < mod[k]; break; } }
+            if (!lt) { g_err = "wire format: coordinate is not a canonical field element"; return GH_E_BAD_ARG; }
+        }
+    }
+    BasesBase* h = nullptr;
+    rc = ops->upload(xy.data(), inf.data(), n_points, 1, &h);
     if (rc) return rc;
     *out_handle = reinterpret_cast<gh_bases_t>(h);
     return GH_OK;

@@ -77,7 +77,7 @@ template <class C> int make_salts(Aff<C>* out) {
 }
 
 template <class C>
-int upload_bases(const uint64_t* bases, const uint8_t* infinity, size_t n, BasesBase** out) {
+int upload_bases(const uint64_t* bases, const uint8_t* infinity, size_t n, int canonical, BasesBase** out) {
     typedef typename C::F F;
     BasesBase* h = new BasesBase();
     h->curve = CurveId<C>::id;
@@ -89,7 +89,7 @@ int upload_bases(const uint64_t* bases, const uint8_t* infinity, size_t n, Bases
         HIPCHK(hipMalloc(&d_in, in_bytes));
         HIPCHK(hipMemcpyAsync(d_in, bases, in_bytes, hipMemcpyHostToDevice, g.stream));
         hipLaunchKernelGGL((msm_convert_bases_kernel<C>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, g.stream,
-                           (const uint32_t*)d_in, (Aff<C>*)h->d_points, n);
+                           (const uint32_t*)d_in, (Aff<C>*)h->d_points, n, canonical);
         HIPCHK(hipGetLastError());
         if (infinity) {
             bool any = false;
@@ -677,7 +677,7 @@ int msm_host(const uint64_t* bases, const uint8_t* infinity, size_t n_bases, con
              uint64_t* out_xyz) {
     size_t n = n_bases < n_scalars ? n_bases : n_scalars;
     BasesBase* h = nullptr;
-    int rc = upload_bases<C>(bases, infinity, n, &h);
+    int rc = upload_bases<C>(bases, infinity, n, 0, &h);
     if (rc) return rc;
     void* d_s = nullptr;
     if (n > 0) {

@@ -76,16 +76,23 @@ __device__ __forceinline__ void st_fp(Fp* p, const Fp& a) {
 #endif
 
 // ---------------------------------------------------------------- bases: ABI -> internal layout
-// in: n x (2 * DEG * 24) words (x || y, Montgomery 2^768); out: n x Aff<C> (internal 2^754)
+// in: n x (2 * DEG * 24) words, x || y, either Montgomery 2^768 (the in-memory form, fp_768.rs:24-30) or --
+// canonical != 0 -- plain integers < p (what ToBytes writes: into_repr(), fp_768.rs:784-789);
+// out: n x Aff<C> (internal 2^754): one product by 2^740 resp. 2^1508 per coefficient.
 template <class C>
-__global__ void __launch_bounds__(256) msm_convert_bases_kernel(const uint32_t* in, Aff<C>* out, size_t n) {
+__global__ void __launch_bounds__(256) msm_convert_bases_kernel(const uint32_t* in, Aff<C>* out, size_t n, int canonical) {
     typedef typename C::F F;
+    typedef typename C::PF PF;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t* p = in + i * (size_t)(48 * F::DEG);
+    const Fp k = canonical ? fp_const<PF>(PF::R2I) : fp_const<PF>(PF::CIN);
     Aff<C> a;
-    a.x = F::from_abi(p);
-    a.y = F::from_abi(p + 24 * F::DEG);
+#pragma unroll
+    for (int d = 0; d < F::DEG; d++) {
+        F::comp(a.x, d) = fp_mul<PF>(fp_unpack(p + 24 * d), k);
+        F::comp(a.y, d) = fp_mul<PF>(fp_unpack(p + 24 * (F::DEG + d)), k);
+    }
     uint2* q = reinterpret_cast<uint2*>(out + i);
     const uint2* s = reinterpret_cast<const uint2*>(&a);
 #pragma unroll

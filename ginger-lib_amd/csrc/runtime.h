@@ -75,7 +75,7 @@ struct BasesBase {
     uint32_t magic = 0x6768424au;
 };
 struct MsmOps {
-    int (*upload)(const uint64_t* bases, const uint8_t* infinity, size_t n, BasesBase** out);
+    int (*upload)(const uint64_t* bases, const uint8_t* infinity, size_t n, int canonical, BasesBase** out);
     int (*run)(BasesBase* h, const void* d_scalars, size_t n_scalars, uint64_t* out_xyz);
     int (*host)(const uint64_t* bases, const uint8_t* infinity, size_t n_bases, const uint64_t* scalars,
                 size_t n_scalars, uint64_t* out_xyz);

@@ -91,6 +91,13 @@ int gh_msm(gh_curve_t curve, const uint64_t* bases, const uint8_t* infinity, siz
 typedef struct gh_bases* gh_bases_t;
 int gh_bases_upload(gh_curve_t curve, const uint64_t* bases, const uint8_t* infinity, size_t n_bases,
                     gh_bases_t* out_handle);
+/* The same from the reference's serialised form, so that a proving key file (Parameters::write,
+ * groth16/mod.rs:188-239) can go to the device query by query without a Montgomery conversion on the host:
+ * n_points records of  x || y || infinity  with every base-field coefficient as 96 little-endian bytes of its
+ * canonical integer (GroupAffine::write, short_weierstrass_projective.rs:185-192; Fp768::write, fp_768.rs:784-789),
+ * i.e. 193 / 385 / 577 bytes per G1 / MNT4-G2 / MNT6-G2 point.  GH_E_BAD_ARG where FromBytes would fail
+ * (a coefficient >= p, a flag byte other than 0 / 1).                                                  */
+int gh_bases_upload_wire(gh_curve_t curve, const uint8_t* bytes, size_t n_points, gh_bases_t* out_handle);
 int gh_bases_free(gh_bases_t handle);
 size_t gh_bases_len(gh_bases_t handle);
 /* Optional, once per resident key: build the shift table 2^(c w) P_i, w = 0 .. floor(752/c), in

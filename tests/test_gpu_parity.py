@@ -430,3 +430,55 @@ def test_msm_affine_bucket_sums_vs_oracle(gpu, curve, n, windows):
     finally:
         gpu.msm_set_affine(0)
         rb.free()
+
+
+# ------------------------------------------------------------------------------ proving-key wire format
+def _wire(C, pts):
+    """GroupAffine::write (short_weierstrass_projective.rs:185-192): x || y || infinity, each base-field
+    coefficient as 96 LE bytes of its canonical integer; zero() = (0, 1, true)."""
+    out = bytearray()
+    for P in pts:
+        x, y = (tuple([0] * C.deg), tuple([1] + [0] * (C.deg - 1))) if P is None else P
+        for coord in (x, y):
+            for c in coord:
+                out += int(c).to_bytes(96, "little")
+        out.append(1 if P is None else 0)
+    return bytes(out)
+
+
+@pytest.mark.parametrize("curve,n", [("mnt4753_g1", 200), ("mnt6753_g1", 100), ("mnt4753_g2", 60), ("mnt6753_g2", 40)])
+def test_bases_upload_wire_vs_oracle(gpu, curve, n):
+    """gh_bases_upload_wire: bases from the reference's serialised form (canonical little-endian coefficients,
+    infinity flag byte) give the same MSM as the same points uploaded as Montgomery limbs, and as the oracle."""
+    C = pyref.CURVES[curve]
+    rng = pyref.Rng(55 + n)
+    pts = S.chain_points(C, n, rng)
+    pts[3] = None
+    scal = [rng.field_elem(C.order) for _ in range(n)]
+    b, inf = S.bases_array(C, pts)
+    s = S.scalar_array(scal)
+    exp = S.oracle_msm(curve, b, inf, s, 8)
+    rb = gpu.ResidentBases.from_wire(curve, _wire(C, pts))
+    assert rb.n == n
+    assert affine_eq(gpu, curve, rb.msm(s), exp)
+    rb.precompute(0)
+    assert affine_eq(gpu, curve, rb.msm(s), exp)
+    rb.free()
+    # what FromBytes rejects: a coefficient >= p (fp_768.rs:791-805), a flag byte that is no bool
+    bad = bytearray(_wire(C, pts[:2]))
+    bad[0:96] = int(C.F.p).to_bytes(96, "little")
+    with pytest.raises(gpu.GingerHipError):
+        gpu.ResidentBases.from_wire(curve, bytes(bad))
+    bad = bytearray(_wire(C, pts[:2]))
+    bad[192 * C.deg] = 2
+    with pytest.raises(gpu.GingerHipError):
+        gpu.ResidentBases.from_wire(curve, bytes(bad))
+
+
+def test_wire_byte_order_matches_reference_fixture():
+    """the reference's own 96-byte fixtures (fields/mnt{4,6}753/test_vec/*_tobyte) are canonical little-endian
+    integers below p -- the convention _wire() and gh_bases_upload_wire use"""
+    kats = json.load(open(os.path.join(G, "ref_kats.json")))
+    for tag, F in (("mnt4753", pyref.P4), ("mnt6753", pyref.P6)):
+        raw = bytes.fromhex(kats["test_vec/%s_tobyte" % tag])
+        assert len(raw) == 96 and int.from_bytes(raw, "little") < F.p
