@@ -47,7 +47,7 @@ a, b, c = (S.random_scalars_np(N, seed=s0, below=r_ord) for s0 in (1, 2, 3))
 d = S.random_scalars_np(3, seed=4, below=r_ord)
 da, db, dc, dh = (gl.DeviceBuffer(N * 96 + 96) for _ in range(4))
 lib = gl.load_library()
-assign = S.random_scalars_np(nv, seed=9, below=r_ord)          # canonical scalars (into_repr of the assignment)
+assign = S.random_scalars_np(nv - 1, seed=9, below=r_ord)      # canonical scalars: inputs (ni - 1) || aux (nv - ni)
 assign[::7] = 0
 assign[1::7, 1:] = 0
 assign[1::7, 0] = 1                                            # witness-like: many 0 / 1
