@@ -252,7 +252,22 @@ def main():
         g_xy, g_inf = gl.proj_to_affine(curve, got)
         e_xy, e_inf = S.oracle_affine(curve, exp)
         parity = bool(g_inf == e_inf and (g_xy == e_xy).all())
+        cpu_model = ""
+        try:
+            for line in open("/proc/cpuinfo"):
+                if line.startswith("model name"):
+                    cpu_model = line.split(":", 1)[1].strip()
+                    break
+        except OSError:
+            pass
+        m1 = min(m, 1 << 12)       # the same algorithm on ONE core, smaller sample (c = 10 at 2^12, 76 windows in sequence)
+        t1 = time.perf_counter()
+        S.oracle_msm(curve, bases[:m1], None, scalars[:m1], 1)
+        cpu1_s = time.perf_counter() - t1
         out["cpu_baseline"] = {"value": m / cpu_s, "unit": "scalar-muls/s", "cores": msm_threads, "host_cores": cores, "kind": "port",
+                               "cpu_model": cpu_model,
+                               "single_core": {"value": m1 / cpu1_s, "unit": "scalar-muls/s", "cores": 1,
+                                               "sample": "first 2^%d pairs, %.2f s" % (int(np.log2(m1)), cpu1_s)},
                                "sample": "oracle (C++ restatement of variable_base.rs:10-83, window-parallel) on the first 2^%d pairs of the same inputs, %.2f s" % (int(np.log2(m)), cpu_s),
                                "gpu_matches_oracle_on_sample": parity}
         if not parity:
