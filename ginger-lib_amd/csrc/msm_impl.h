@@ -407,11 +407,14 @@ struct MsmJob {
     int launch_sort(hipStream_t st) {
         if (n == 0) return GH_OK;
         int rc;
+        // keys a wave combines into one atomic each before falling back to per-lane atomics (wave_agg_inc)
+        static const int env_agg = getenv("GH_AGG_ITERS") ? atoi(getenv("GH_AGG_ITERS")) : -1;
+        const int agg_iters = env_agg >= 0 ? env_agg : 12;
         HIPCHK(hipEventRecord(g.pev[slot][0], st));
         HIPCHK(hipMemsetAsync(counts, 0, total * 4, st));
         HIPCHK(hipMemsetAsync(size_hist, 0, MSM_SIZE_BINS * 4, st));
         hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
-                           (const uint32_t*)d_scalars, (const uint8_t*)h->d_inf, n, c, W, win_stride, top_unsigned, scalar_modulus<C>(), digits, counts);
+                           (const uint32_t*)d_scalars, (const uint8_t*)h->d_inf, n, c, W, win_stride, top_unsigned, scalar_modulus<C>(), digits, counts, agg_iters);
         HIPCHK(hipGetLastError());
         if ((rc = device_scan(counts, starts, total, "scan_tmp"))) return rc;
         HIPCHK(hipMemcpyAsync(cursor, starts, total * 4, hipMemcpyDeviceToDevice, st));
@@ -421,7 +424,7 @@ struct MsmJob {
         hipLaunchKernelGGL(msm_heavy_plan_kernel, dim3(1), dim3(1), 0, st, (const uint32_t*)size_hist, (const uint32_t*)counts,
                            (const uint32_t*)order, (const uint32_t*)starts, (uint32_t)total, heavy_chunk, chunk_start, plan);
         hipLaunchKernelGGL(msm_scatter_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)W), dim3(256), 0, st,
-                           (const int32_t*)digits, n, W, win_stride, merged ? (uint32_t)h->n : 0u, cursor, sorted);
+                           (const int32_t*)digits, n, W, win_stride, merged ? (uint32_t)h->n : 0u, cursor, sorted, agg_iters);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(hplan, plan, 16, hipMemcpyDeviceToHost, st));
         HIPCHK(hipEventRecord(g.pev[slot][1], st));

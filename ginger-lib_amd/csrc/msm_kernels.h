@@ -261,7 +261,7 @@ struct MsmModulus { uint32_t w[24]; };
 static __global__ void __launch_bounds__(256)
 msm_digits_kernel(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ infinity, size_t n, int c,
                   int num_windows, uint32_t win_stride, int top_unsigned, MsmModulus r,
-                  int32_t* __restrict__ digits, uint32_t* __restrict__ counts) {
+                  int32_t* __restrict__ digits, uint32_t* __restrict__ counts, int agg_iters) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = i < n;
     uint32_t s[25];
@@ -312,7 +312,7 @@ msm_digits_kernel(const uint32_t* __restrict__ scalars, const uint8_t* __restric
         if (skip) d = 0;
         if (valid) digits[(size_t)w * n + i] = d;
         const uint32_t mag = d < 0 ? (uint32_t)(-d) : (uint32_t)d;
-        wave_agg_inc(counts + (size_t)w * win_stride, mag, d != 0, 12);
+        wave_agg_inc(counts + (size_t)w * win_stride, mag, d != 0, agg_iters);
     }
 }
 
@@ -370,12 +370,12 @@ static __global__ void msm_heavy_plan_kernel(const uint32_t* size_hist, const ui
 static __global__ void __launch_bounds__(256)
 msm_scatter_kernel(const int32_t* __restrict__ digits, size_t n, int num_windows, uint32_t win_stride,
                    uint32_t row_stride /* 0, or the table's row length (merged windows) */,
-                   uint32_t* __restrict__ cursor /* = copy of starts */, uint32_t* __restrict__ sorted) {
+                   uint32_t* __restrict__ cursor /* = copy of starts */, uint32_t* __restrict__ sorted, int agg_iters) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     int w = blockIdx.y;
     const int32_t d = i < n ? digits[(size_t)w * n + i] : 0;
     const uint32_t mag = d < 0 ? (uint32_t)(-d) : (uint32_t)d;
-    const uint32_t pos = wave_agg_inc(cursor + (size_t)w * win_stride, mag, d != 0, 12);
+    const uint32_t pos = wave_agg_inc(cursor + (size_t)w * win_stride, mag, d != 0, agg_iters);
     if (d != 0) sorted[pos] = ((uint32_t)i + (uint32_t)w * row_stride) | (d < 0 ? 0x80000000u : 0u);
 }
 

@@ -274,6 +274,22 @@ def test_msm_full_size_properties(gpu):
     k = 1 << 14
     exp = S.oracle_msm(curve, bases[:k], None, s[:k], 16)
     assert affine_eq(gpu, curve, rb.msm(s[:k]), exp)
+    # the same key with its shift table (one bucket set, c = 21) and as a pipelined batch: same affine results
+    assert rb.precompute(0) == 21
+    xy, inf = gpu.proj_to_affine(curve, rb.msm(s))
+    assert gpu.msm_last_timing()["num_windows"] == 36
+    assert inf == ref_inf and (xy == ref_xy).all()
+    ds, dt = gpu.DeviceBuffer(s.nbytes).upload(s), gpu.DeviceBuffer(t.nbytes).upload(t)
+    outs = gpu.msm_batch_dev([(rb, ds, n), (rb, dt, m), (rb, ds, m), (rb, ds, n)])
+    for o in (outs[0], outs[3]):
+        xy, inf = gpu.proj_to_affine(curve, o)
+        assert inf == ref_inf and (xy == ref_xy).all()
+    for o, r0 in ((outs[1], mt), (outs[2], ms)):
+        a1, i1 = gpu.proj_to_affine(curve, o)
+        a2, i2 = gpu.proj_to_affine(curve, r0)
+        assert i1 == i2 and (a1 == a2).all()
+    assert affine_eq(gpu, curve, rb.msm(s[:k]), exp)
+    ds.free(); dt.free()
     rb.free()
 
 
