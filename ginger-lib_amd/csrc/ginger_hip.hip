@@ -316,7 +316,7 @@ int gh_msm_set_window(int c) {
 }
 int gh_msm_set_affine(int on) {
     std::lock_guard<std::mutex> lk(g_mu);
-    g.affine_mode = on == 2 ? 2 : (on ? 1 : 0);
+    g.affine_mode = (on == 2 || on == 3) ? on : (on ? 1 : 0);
     return GH_OK;
 }
 int gh_msm_get_window(gh_curve_t curve, size_t n) {

@@ -459,7 +459,34 @@ struct MsmJob {
         static const bool affine_env2 = getenv("GH_AFFINE") != nullptr && atoi(getenv("GH_AFFINE")) == 2;
         bool affine = false;
         if constexpr (C::F::DEG == 1) affine = merged && (affine_env || g.affine_mode != 0);
-        if (affine) {
+        static const bool affine_env3 = getenv("GH_AFFINE") != nullptr && atoi(getenv("GH_AFFINE")) == 3;
+        if (affine && (g.affine_mode == 3 || affine_env3)) {
+            if constexpr (C::F::DEG == 1) {   // 4e: one bucket per lane, its pairs in affine
+                const uint32_t n_entries = hplan[2];
+                Fp* prefix;
+                uint32_t *flags, *flist, *fcount;
+                if ((rc = pool_get("aff_prefix", ((size_t)n_entries / 2 + total + 8) * sizeof(Fp), (void**)&prefix))) return rc;
+                if ((rc = pool_get("aff_flags", total * 4, (void**)&flags))) return rc;
+                if ((rc = pool_get("aff_flist", total * 4, (void**)&flist))) return rc;
+                if ((rc = pool_get("aff_fcount", 16, (void**)&fcount))) return rc;
+                HIPCHK(hipMemsetAsync(flags, 0, total * 4, st));
+                HIPCHK(hipMemsetAsync(fcount, 0, 16, st));
+                if (n_chunks > 0)   // chunks of the heavy buckets stay projective
+                    hipLaunchKernelGGL((msm_accumulate_kernel<C, 2>), dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, st,
+                                       (const Aff<C>*)src_points, (const uint32_t*)sorted, (const uint32_t*)starts,
+                                       (const uint32_t*)counts, (const uint32_t*)order, n_heavy, (const Aff<C>*)salts, buckets,
+                                       (const uint32_t*)chunk_start, n_heavy, n_chunks, heavy_chunk, partials, (const uint32_t*)nullptr);
+                hipLaunchKernelGGL((msm_accumulate_pair_kernel<C>), dim3((unsigned)((total - n_heavy + 255) / 256)), dim3(256), 0, st,
+                                   (const Aff<C>*)src_points, (const uint32_t*)sorted, (const uint32_t*)starts, (const uint32_t*)counts,
+                                   (const uint32_t*)order, n_heavy, (uint32_t)total, prefix, flags, buckets);
+                hipLaunchKernelGGL(msm_collect_flagged_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                                   (const uint32_t*)flags, (uint32_t)total, flist, fcount);
+                hipLaunchKernelGGL((msm_accumulate_kernel<C, 2>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                                   (const Aff<C>*)src_points, (const uint32_t*)sorted, (const uint32_t*)starts,
+                                   (const uint32_t*)counts, (const uint32_t*)flist, 0u, (const Aff<C>*)salts, buckets,
+                                   (const uint32_t*)chunk_start, 0u, 0u, heavy_chunk, partials, (const uint32_t*)fcount);
+            }
+        } else if (affine) {
             if constexpr (C::F::DEG == 1) {
                 const uint32_t n_entries = hplan[2];
                 uint32_t n_lanes = (uint32_t)g.num_cus * 512u;              // 2 blocks of 256 per CU

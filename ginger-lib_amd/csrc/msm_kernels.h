@@ -1039,6 +1039,97 @@ __global__ void __launch_bounds__(256, 2) msm_pair_madd_kernel(AffTreeArgs<C> a)
     }
 }
 
+// ---------------------------------------------------------------- 4e. the pair round, one bucket per lane
+// Same arithmetic as 4d, but with the task structure of msm_accumulate_kernel: one whole bucket per lane,
+// buckets walked longest first, so the lanes of a wave run the same number of pairs and never wait for each
+// other.  A lane's running products cover only its own bucket (~18 pairs at 2^20: the inversion costs ~2.4
+// products per pair), stored at prefix[(starts[g] >> 1) + j].  Chunks of heavy buckets stay with the
+// projective kernel; equal x in a pair / the accumulator meeting its own value flag the bucket for it.
+template <class C>
+__global__ void __launch_bounds__(256, 2)
+msm_accumulate_pair_kernel(const Aff<C>* __restrict__ table, const uint32_t* __restrict__ sorted,
+                           const uint32_t* __restrict__ starts, const uint32_t* __restrict__ counts,
+                           const uint32_t* __restrict__ order, uint32_t n_heavy, uint32_t total,
+                           Fp* __restrict__ prefix, uint32_t* __restrict__ flags, Proj<C>* __restrict__ buckets) {
+    typedef typename C::F F;
+    typedef typename F::T FT;
+    static_assert(F::DEG == 1, "pair kernel: prime-field curves");
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total - n_heavy) return;
+    const uint32_t g = order[n_heavy + t];
+    const uint32_t beg = starts[g], cnt = counts[g], half = cnt >> 1;
+    Fp* const pre = prefix + (beg >> 1);
+    __shared__ uint32_t park[NL][256];
+    auto pt_of = [&](uint32_t e) -> Aff<C> {
+        Aff<C> q = ld_aff16<C>(table + (e & 0x7FFFFFFFu));
+        if (e >> 31) q.y = F::neg(q.y);
+        return q;
+    };
+    auto x_of = [&](uint32_t e) -> FT { return ld_fp(reinterpret_cast<const Fp*>(table + (e & 0x7FFFFFFFu))); };
+    FT acc = F::one();
+    for (uint32_t j = 0; j < half; j++) {
+        FT d = F::sub(x_of(sorted[beg + 2 * j + 1]), x_of(sorted[beg + 2 * j]));
+        if (F::is_zero(d)) { flags[g] = 1u; d = F::one(); }
+        acc = F::mul(acc, d);
+        st_fp(pre + j, acc);
+    }
+    FT inv = F::one();
+    if (half > 0) inv = fp_inv<typename C::PF>(acc);
+    Proj<C> P = proj_zero<C>();
+    if (cnt & 1u) { const Aff<C> q = pt_of(sorted[beg + cnt - 1]); P.x = q.x; P.y = q.y; P.z = F::one(); }
+    for (uint32_t j = half; j-- > 0;) {
+        const Aff<C> p1 = pt_of(sorted[beg + 2 * j]), p2 = pt_of(sorted[beg + 2 * j + 1]);
+        FT d = F::sub(p2.x, p1.x);
+        if (F::is_zero(d)) d = F::one();
+        FT dinv = inv;
+        if (j > 0) dinv = F::mul(inv, ld_fp(pre + j - 1));
+        inv = F::mul(inv, d);
+        const FT lam = F::mul(F::sub(p2.y, p1.y), dinv);
+        Aff<C> q;
+        q.x = F::sub(F::sub(F::sqr(lam), p1.x), p2.x);
+        q.y = F::sub(F::mul(lam, F::sub(p1.x, q.x)), p1.y);
+        if (proj_is_zero<C>(P)) {
+            P.x = q.x; P.y = q.y; P.z = F::one();
+        } else {   // madd-1998-cmo (swp.rs:497-517), operation order as in msm_accumulate_kernel
+            FT v = F::mul(q.x, P.z);
+            FT u = F::mul(q.y, P.z);
+            if (F::eq(u, P.y) && F::eq(v, P.x)) flags[g] = 1u;
+            u = F::sub(u, P.y);
+            v = F::sub(v, P.x);
+            {
+                const uint32_t* yw = reinterpret_cast<const uint32_t*>(&P.y);
+#pragma unroll
+                for (int w = 0; w < NL; w++) park[w][threadIdx.x] = yw[w];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            FT vv = F::sqr(v);
+            __builtin_amdgcn_sched_barrier(0);
+            FT r = F::mul(vv, P.x);
+            __builtin_amdgcn_sched_barrier(0);
+            FT vvv = F::mul(v, vv);
+            __builtin_amdgcn_sched_barrier(0);
+            FT uu = F::sqr(u);
+            __builtin_amdgcn_sched_barrier(0);
+            FT aa = F::sub(F::sub(F::mul(uu, P.z), vvv), F::dbl(r));
+            __builtin_amdgcn_sched_barrier(0);
+            P.x = F::mul(v, aa);
+            __builtin_amdgcn_sched_barrier(0);
+            FT rma = F::sub(r, aa);
+            __builtin_amdgcn_sched_barrier(0);
+            FT y1;
+            {
+                uint32_t* yw = reinterpret_cast<uint32_t*>(&y1);
+#pragma unroll
+                for (int w = 0; w < NL; w++) yw[w] = park[w][threadIdx.x];
+            }
+            P.y = F::sub(F::mul(u, rma), F::mul(vvv, y1));
+            __builtin_amdgcn_sched_barrier(0);
+            P.z = F::mul(vvv, P.z);
+        }
+    }
+    st_proj<C>(buckets + g, P);
+}
+
 // flagged buckets -> list for the projective kernel (dyn_total = n[0])
 static __global__ void __launch_bounds__(256)
 msm_collect_flagged_kernel(const uint32_t* __restrict__ flags, uint32_t total, uint32_t* __restrict__ list, uint32_t* __restrict__ n) {

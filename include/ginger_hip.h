@@ -130,7 +130,9 @@ int gh_msm_get_window(gh_curve_t curve, size_t n);
 /* Experimental (default off): on a G1 key with a shift table, sum the buckets in AFFINE coordinates --
  * pairwise rounds, one safegcd inversion per lane and round via Montgomery's trick (~6 field products
  * per addition instead of 11); additions with equal x and over-long buckets fall back to the projective
- * kernel.  Same results; currently slower than the projective kernel.        */
+ * kernel.  Same results; currently slower than the projective kernel.
+ * on: 0 off, 1 pairwise rounds all in affine, 2 one affine round + mixed additions over lane slices,
+ * 3 the same with one bucket per lane.                                                              */
 int gh_msm_set_affine(int on);
 
 /* Time spent by the last MSM call in its phases, milliseconds (device phases by HIP events on the

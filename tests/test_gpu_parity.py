@@ -436,7 +436,7 @@ def test_msm_affine_bucket_sums_vs_oracle(gpu, curve, n, windows):
         for c in windows:
             rb.precompute(c)
             exp_short = S.oracle_msm(curve, b, inf, s[:n // 2], 16)
-            for mode in (1, 2):               # 1: pairwise rounds, all in affine (4c); 2: one affine round + mixed additions (4d)
+            for mode in (1, 2, 3):            # 1: pairwise rounds (4c); 2: one affine round + mixed additions, lane slices (4d); 3: the same, one bucket per lane (4e)
                 gpu.msm_set_affine(mode)
                 got = rb.msm(s)
                 assert affine_eq(gpu, curve, got, exp), (curve, c, "affine mode", mode)
