@@ -1045,8 +1045,11 @@ __global__ void __launch_bounds__(256, 2) msm_pair_madd_kernel(AffTreeArgs<C> a)
 // other.  A lane's running products cover only its own bucket (~18 pairs at 2^20: the inversion costs ~2.4
 // products per pair), stored at prefix[(starts[g] >> 1) + j].  Chunks of heavy buckets stay with the
 // projective kernel; equal x in a pair / the accumulator meeting its own value flag the bucket for it.
+#ifndef GH_PAIR_WAVES
+#define GH_PAIR_WAVES 2
+#endif
 template <class C>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(256, GH_PAIR_WAVES)
 msm_accumulate_pair_kernel(const Aff<C>* __restrict__ table, const uint32_t* __restrict__ sorted,
                            const uint32_t* __restrict__ starts, const uint32_t* __restrict__ counts,
                            const uint32_t* __restrict__ order, uint32_t n_heavy, uint32_t total,
