@@ -1,6 +1,9 @@
+"""Latency of tiny MSMs (1..64 pairs) through gh_msm and of one host-side gh_proj_mul: what the prover's
+2-pair "inputs" MSMs would cost if they were issued on their own (ginger-lib_amd/groth16.py folds them into
+the large queries instead)."""
 import os, sys, time
 import numpy as np
-ROOT = "/root/repo"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import pyref, support as S
 from __graft_entry__ import _load_pkg
