@@ -10,6 +10,10 @@
 #include "msm_kernels.h"
 #include "host_math.h"
 
+#ifndef GH_F3S_TRIPLE
+#define GH_F3S_TRIPLE 0   // Fq3 accumulation: 0 = three plain products in a rolled loop, 2 waves/SIMD; 1 = triple product with one
+                         // reduction (fp_mul3, host-tested), unrolled, 1 wave/SIMD -- hipcc did not finish that kernel in 25 minutes
+#endif
 #ifndef GH_F2S_DUAL
 #define GH_F2S_DUAL 1   // Fq2 accumulation: 1 = dual product at 1 wave/SIMD (119 ms at 2^20 pairs); 0 = two plain products per
                         // lane at 2 waves/SIMD, measured 166 ms (1.8 KB of spills: both shuffled operand sets stay live)
@@ -548,7 +552,7 @@ struct MsmJob {
             constexpr bool is_g2 = std::is_same<C, Mnt4G2>::value || std::is_same<C, Mnt6G2>::value;
             if constexpr (is_g2) {
                 if (!no_split) {
-                    typedef typename std::conditional<std::is_same<C, Mnt4G2>::value, F2S<P4, 13, GH_F2S_DUAL != 0>, F3S<P6, 11>>::type FS;
+                    typedef typename std::conditional<std::is_same<C, Mnt4G2>::value, F2S<P4, 13, GH_F2S_DUAL != 0>, F3S<P6, 11, GH_F3S_TRIPLE != 0>>::type FS;
                     constexpr int LANES = FS::LANES;
                     const size_t waves = (tasks + (64 / LANES) - 1) / (64 / LANES);
                     hipLaunchKernelGGL((msm_accumulate_split_kernel<C, FS, LANES>), dim3((unsigned)((waves * 64 + 255) / 256)), dim3(256), 0, st,

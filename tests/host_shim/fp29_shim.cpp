@@ -85,7 +85,15 @@ template <class HC> static void h64_ec(int op, const uint64_t* p, const uint64_t
 template <class P> static void fp_mul2_op(const uint32_t* a, const uint32_t* b, const uint32_t* c, const uint32_t* d, uint32_t* out) {
     fp_pack(out, fp_mul2<P>(fp_unpack(a), fp_unpack(b), fp_unpack(c), fp_unpack(d)));
 }
+template <class P> static void fp_mul3_op(const uint32_t* a, const uint32_t* b, const uint32_t* c, const uint32_t* d, const uint32_t* e,
+                                           const uint32_t* f, uint32_t* out) {
+    fp_pack(out, fp_mul3<P>(fp_unpack(a), fp_unpack(b), fp_unpack(c), fp_unpack(d), fp_unpack(e), fp_unpack(f)));
+}
 extern "C" {
+void t_fp_mul3(int field, const uint32_t* a, const uint32_t* b, const uint32_t* c, const uint32_t* d, const uint32_t* e,
+               const uint32_t* f, uint32_t* out) {
+    if (field == 4) fp_mul3_op<P4>(a, b, c, d, e, f, out); else fp_mul3_op<P6>(a, b, c, d, e, f, out);
+}
 void t_fp_mul2(int field, const uint32_t* a, const uint32_t* b, const uint32_t* c, const uint32_t* d, uint32_t* out) {
     if (field == 4) fp_mul2_op<P4>(a, b, c, d, out); else fp_mul2_op<P6>(a, b, c, d, out);
 }

@@ -58,6 +58,12 @@ def test_field_ops(shim, fid, F):
         c, d = (p - 1, p - 1) if it < 4 else (rng.field_elem(p), rng.field_elem(p))
         shim.t_fp_mul2(fid, words(a), words(b), words(c), words(d), out)
         assert toint(out) == ((a * b + c * d) * RIinv) % p, it
+        # triple product with one reduction; extremes (all p - 1: the value passes 2^754) included
+        e, f = (p - 1, p - 1) if it < 6 else (rng.field_elem(p), rng.field_elem(p))
+        if it in (4, 5):
+            a = b = c = d = p - 1
+        shim.t_fp_mul3(fid, words(a), words(b), words(c), words(d), words(e), words(f), out)
+        assert toint(out) == ((a * b + c * d + e * f) * RIinv) % p, it
 
 
 @pytest.mark.parametrize("fid,F", [(4, pyref.P4), (6, pyref.P6)])
