@@ -25,6 +25,19 @@ def run(gl):
     e_xy, e_inf = S.oracle_affine("mnt4753_g1", exp)
     assert g_inf == e_inf and (g_xy == e_xy).all(), "MSM mismatch vs oracle"
     print("[smoke] msm ok", gl.msm_last_timing())
+    # --- the same key resident with its shift table, two MSMs as one pipelined batch (the bench's path)
+    rb = gl.ResidentBases("mnt4753_g1", b, inf)
+    c = rb.precompute(0)
+    ds = gl.DeviceBuffer(s.nbytes).upload(s)
+    outs = gl.msm_batch_dev([(rb, ds, n), (rb, ds, n - 100)])
+    exp2 = S.oracle_msm("mnt4753_g1", b, inf, s[:n - 100], 4)
+    for o, e in ((outs[0], exp), (outs[1], exp2)):
+        g_xy, g_inf = gl.proj_to_affine("mnt4753_g1", o)
+        e_xy, e_inf = S.oracle_affine("mnt4753_g1", e)
+        assert g_inf == e_inf and (g_xy == e_xy).all(), "table / batch MSM mismatch vs oracle"
+    ds.free()
+    rb.free()
+    print("[smoke] msm on shift table (c = %d), pipelined batch ok" % c)
     # --- NTT: MNT4-753 Fr, 2^10, all four transforms
     F = pyref.P6
     a = S.fe_array(F, [rng.field_elem(F.p) for _ in range(1000)])   # padded to 1024

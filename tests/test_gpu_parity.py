@@ -498,3 +498,29 @@ def test_wire_byte_order_matches_reference_fixture():
     for tag, F in (("mnt4753", pyref.P4), ("mnt6753", pyref.P6)):
         raw = bytes.fromhex(kats["test_vec/%s_tobyte" % tag])
         assert len(raw) == 96 and int.from_bytes(raw, "little") < F.p
+
+
+def test_msm_batch_argument_errors(gpu):
+    """a batch stays on one curve; bad handles and null arguments are reported, nothing is left in flight"""
+    import ctypes
+    C1, C2 = pyref.CURVES["mnt4753_g1"], pyref.CURVES["mnt6753_g1"]
+    rng = pyref.Rng(1)
+    b1, _ = S.bases_array(C1, S.chain_points(C1, 8, rng))
+    b2, _ = S.bases_array(C2, S.chain_points(C2, 8, rng))
+    r1, r2 = gpu.ResidentBases("mnt4753_g1", b1), gpu.ResidentBases("mnt6753_g1", b2)
+    s = S.scalar_array([rng.field_elem(C1.order) for _ in range(8)])
+    d = gpu.DeviceBuffer(s.nbytes).upload(s)
+    with pytest.raises(gpu.GingerHipError):
+        gpu.msm_batch_dev([(r1, d, 8), (r2, d, 8)])
+    lib = gpu.load_library()
+    out = np.zeros(36, dtype=np.uint64)
+    bad = (ctypes.c_void_p * 1)(ctypes.c_void_p(0))
+    ptrs = (ctypes.c_void_p * 1)(d.ptr)
+    ns = (ctypes.c_size_t * 1)(8)
+    assert lib.gh_msm_resident_dev_batch(bad, ptrs, ns, 1, out.ctypes.data_as(ctypes.c_void_p)) == -6      # GH_E_BAD_HANDLE
+    assert lib.gh_msm_resident_dev_batch(None, ptrs, ns, 1, out.ctypes.data_as(ctypes.c_void_p)) == -1     # GH_E_BAD_ARG
+    assert lib.gh_msm_resident_dev_batch(None, None, None, 0, None) == 0
+    # the library is still usable afterwards
+    exp = S.oracle_msm("mnt4753_g1", b1, None, s, 4)
+    assert affine_eq(gpu, "mnt4753_g1", gpu.msm_batch_dev([(r1, d, 8)])[0], exp)
+    d.free(); r1.free(); r2.free()
