@@ -34,9 +34,13 @@ ABI_SYMBOLS = [
     "gh_msm_set_window", "gh_msm_set_affine", "gh_msm_get_window", "gh_msm_last_timing", "gh_msm_batch_timing",
     "gh_domain_supported", "gh_fft", "gh_fft_dev", "gh_vec_mul_dev", "gh_vec_sub_dev", "gh_vec_scale_dev",
     "gh_vec_mul", "gh_vec_scale", "gh_fft_last_kernel_ms", "gh_witness_map", "gh_witness_map_dev",
-    "gh_dev_alloc", "gh_dev_free", "gh_dev_upload", "gh_dev_download", "gh_dev_sync",
+    "gh_dev_alloc", "gh_dev_free", "gh_dev_upload", "gh_dev_download", "gh_dev_sync", "gh_dev_trim",
     "gh_proj_add", "gh_proj_mul", "gh_proj_neg", "gh_proj_to_affine",
 ]
+# include/ginger_hip_dist.h
+DIST_SYMBOLS = ["gh_dist_unique_id", "gh_dist_init_rccl", "gh_dist_init_custom", "gh_dist_info", "gh_partials_allgather_fold",
+                "gh_dist_shutdown"]
+ALLGATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t)
 
 
 class GingerHipError(RuntimeError):
@@ -61,7 +65,7 @@ def load_library():
     if not os.path.exists(LIB_PATH):
         raise GingerHipError("HIP library not built: %s (run `python __graft_entry__.py`)" % LIB_PATH)
     lib = ctypes.CDLL(LIB_PATH)
-    missing = [s for s in ABI_SYMBOLS if not hasattr(lib, s)]
+    missing = [s for s in ABI_SYMBOLS + DIST_SYMBOLS if not hasattr(lib, s)]
     if missing:
         raise GingerHipError("libginger_hip.so lacks ABI symbols: %s" % missing)
     vp, sz, u32, ci = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_int
@@ -103,6 +107,11 @@ def load_library():
     lib.gh_proj_mul.argtypes = [ci, vp, vp, vp]
     lib.gh_proj_neg.argtypes = [ci, vp]
     lib.gh_proj_to_affine.argtypes = [ci, vp, vp, vp]
+    lib.gh_dist_unique_id.argtypes = [vp]
+    lib.gh_dist_init_rccl.argtypes = [vp, ci, ci]
+    lib.gh_dist_init_custom.argtypes = [ALLGATHER_FN, vp, ci, ci]
+    lib.gh_dist_info.argtypes = [ctypes.POINTER(ci), ctypes.POINTER(ci)]
+    lib.gh_partials_allgather_fold.argtypes = [ci, vp, vp, ctypes.POINTER(ctypes.c_double)]
     _lib = lib
     return lib
 
@@ -259,8 +268,13 @@ def msm_set_window(c):
     _check(load_library().gh_msm_set_window(int(c)))
 
 
-def msm_set_affine(on):
-    _check(load_library().gh_msm_set_affine(int(on)))
+def msm_set_affine(mode):
+    """0: projective bucket sums, 1: affine rounds always, 2: automatic (default)."""
+    _check(load_library().gh_msm_set_affine(int(mode)))
+
+
+def dev_trim():
+    _check(load_library().gh_dev_trim())
 
 
 def msm_last_timing():

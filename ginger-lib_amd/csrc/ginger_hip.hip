@@ -13,6 +13,7 @@ Ctx g;
 std::string g_err;
 static std::mutex g_mu;
 static char g_devname[256] = "";
+static int g_device_req = -1;   // gh_init(devices): explicit device index; -1 = $LOCAL_RANK (or 0)
 
 int ensure_init() {
     if (g.ready) return GH_OK;
@@ -24,7 +25,8 @@ int ensure_init() {
     }
     int dev = 0;
     const char* lr = getenv("LOCAL_RANK");
-    if (lr) dev = atoi(lr) % count;
+    if (g_device_req >= 0) dev = g_device_req;
+    else if (lr) dev = atoi(lr) % count;
     g.device = dev;
     HIPCHK(hipSetDevice(dev));
     hipDeviceProp_t prop;
@@ -61,16 +63,17 @@ int pool_get(const char* name, size_t bytes, void** out) {
 }
 
 // generic exclusive scan of n u32 on the library stream
-int device_scan(const uint32_t* in, uint32_t* out, size_t n, const char* tmpname) {
+int device_scan(const uint32_t* in, uint32_t* out, size_t n, const char* tmpname, hipStream_t stream) {
     using namespace gh;
+    if (!stream) stream = g.stream;
     size_t per_block = (size_t)SCAN_BLOCK * SCAN_ITEMS;
     size_t nblocks = (n + per_block - 1) / per_block;
     uint32_t* sums;
     int rc = pool_get(tmpname, (nblocks + 1) * 4, (void**)&sums);
     if (rc) return rc;
-    hipLaunchKernelGGL(scan_partials_kernel, dim3((unsigned)nblocks), dim3(SCAN_BLOCK), 0, g.stream, in, sums, n);
-    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, g.stream, sums, nblocks);
-    hipLaunchKernelGGL(scan_final_kernel, dim3((unsigned)nblocks), dim3(SCAN_BLOCK), 0, g.stream, in, sums, out, n);
+    hipLaunchKernelGGL(scan_partials_kernel, dim3((unsigned)nblocks), dim3(SCAN_BLOCK), 0, stream, in, sums, n);
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, stream, sums, nblocks);
+    hipLaunchKernelGGL(scan_final_kernel, dim3((unsigned)nblocks), dim3(SCAN_BLOCK), 0, stream, in, sums, out, n);
     HIPCHK(hipGetLastError());
     return GH_OK;
 }
@@ -119,8 +122,7 @@ int gh_init(const int* devices, int n_devices) {
         int count = 0;
         if (hipGetDeviceCount(&count) != hipSuccess || count == 0) { g_err = "no HIP device visible"; return GH_E_NO_DEVICE; }
         if (devices[0] < 0 || devices[0] >= count) { g_err = "device index out of range"; return GH_E_BAD_ARG; }
-        char b[16]; snprintf(b, sizeof b, "%d", devices[0]);
-        setenv("LOCAL_RANK", b, 1);
+        g_device_req = devices[0];
     }
     return ensure_init();
 }
@@ -129,8 +131,12 @@ int gh_shutdown(void) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (!g.ready) return GH_OK;
     hipStreamSynchronize(g.stream);
+    hipStreamSynchronize(g.stream_acc);
+    hipStreamSynchronize(g.stream_red);
     for (auto& kv : g.pool) if (kv.second.p) hipFree(kv.second.p);
     g.pool.clear();
+    for (auto& f : g.at_shutdown) f();   // function-local device / pinned allocations (msm_impl.h)
+    g.at_shutdown.clear();
     for (int f = 0; f < 2; f++) {
         for (auto& kv : g.domains[f]) {
             Domain& d = kv.second;
@@ -143,8 +149,6 @@ int gh_shutdown(void) {
     }
     for (auto& ev : g.ev) hipEventDestroy(ev);
     for (auto& sl : g.pev) for (auto& ev : sl) hipEventDestroy(ev);
-    hipStreamSynchronize(g.stream_acc);
-    hipStreamSynchronize(g.stream_red);
     hipStreamDestroy(g.stream_acc);
     hipStreamDestroy(g.stream_red);
     hipStreamDestroy(g.stream);
@@ -152,7 +156,12 @@ int gh_shutdown(void) {
     return GH_OK;
 }
 
-const char* gh_last_error(void) { return g_err.c_str(); }
+const char* gh_last_error(void) {
+    static thread_local std::string tl;
+    std::lock_guard<std::mutex> lk(g_mu);
+    tl = g_err;
+    return tl.c_str();
+}
 const char* gh_device_name(void) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (ensure_init()) return "";
@@ -289,23 +298,23 @@ int gh_msm_resident_dev_batch(const gh_bases_t* handles, const void* const* d_sc
 }
 
 int gh_msm_resident(gh_bases_t handle, const uint64_t* scalars, size_t n_scalars, uint64_t* out_xyz) {
+    // ONE critical section from staging the scalars to the result: the staging buffer is a shared pool slot
+    std::lock_guard<std::mutex> lk(g_mu);
+    BasesBase* h = reinterpret_cast<BasesBase*>(handle);
+    if (!h || h->magic != 0x6768424au) { g_err = "bad bases handle"; return GH_E_BAD_HANDLE; }
+    if (!out_xyz || (n_scalars && !scalars)) { g_err = "null argument"; return GH_E_BAD_ARG; }
+    const MsmOps* ops = ops_of(h->curve);
+    if (!ops) return GH_E_BAD_ARG;
+    int rc = ensure_init();
+    if (rc) return rc;
+    const size_t n = h->n < n_scalars ? h->n : n_scalars;
     void* d_s = nullptr;
-    size_t n = 0;
-    {
-        std::lock_guard<std::mutex> lk(g_mu);
-        BasesBase* h = reinterpret_cast<BasesBase*>(handle);
-        if (!h || h->magic != 0x6768424au) { g_err = "bad bases handle"; return GH_E_BAD_HANDLE; }
-        if (!out_xyz || (n_scalars && !scalars)) { g_err = "null argument"; return GH_E_BAD_ARG; }
-        int rc = ensure_init();
+    if (n > 0) {
+        rc = pool_get("scalars", n * 96, &d_s);
         if (rc) return rc;
-        n = h->n < n_scalars ? h->n : n_scalars;
-        if (n > 0) {
-            rc = pool_get("scalars", n * 96, &d_s);
-            if (rc) return rc;
-            HIPCHK(hipMemcpyAsync(d_s, scalars, n * 96, hipMemcpyHostToDevice, g.stream));
-        }
+        HIPCHK(hipMemcpyAsync(d_s, scalars, n * 96, hipMemcpyHostToDevice, g.stream));
     }
-    return gh_msm_resident_dev(handle, n ? d_s : (const void*)scalars, n, out_xyz);
+    return ops->run(h, d_s, n, out_xyz);
 }
 
 int gh_msm_set_window(int c) {
@@ -316,7 +325,8 @@ int gh_msm_set_window(int c) {
 }
 int gh_msm_set_affine(int on) {
     std::lock_guard<std::mutex> lk(g_mu);
-    g.affine_mode = (on == 2 || on == 3) ? on : (on ? 1 : 0);
+    if (on < 0 || on > 2) { g_err = "affine mode must be 0 (off), 1 (on) or 2 (automatic)"; return GH_E_BAD_ARG; }
+    g.affine_mode = on;
     return GH_OK;
 }
 int gh_msm_get_window(gh_curve_t curve, size_t n) {
@@ -353,25 +363,23 @@ int gh_fft_dev(gh_field_t field, void* d_data, uint32_t log_n, uint32_t flags) {
 }
 
 int gh_fft(gh_field_t field, const uint64_t* in, size_t n_in, uint64_t* out, uint32_t log_n, uint32_t flags) {
-    if (!out || (n_in && !in)) { g_err = "null argument"; return GH_E_BAD_ARG; }
-    if (log_n >= 31) { g_err = "domain too large"; return GH_E_UNSUPPORTED; }
+    if (!out || (n_in && !in)) { std::lock_guard<std::mutex> lk(g_mu); g_err = "null argument"; return GH_E_BAD_ARG; }
+    if (log_n >= 31) { std::lock_guard<std::mutex> lk(g_mu); g_err = "domain too large"; return GH_E_UNSUPPORTED; }
     const size_t N = (size_t)1 << log_n;
-    void* d = nullptr;
-    {
-        std::lock_guard<std::mutex> lk(g_mu);
-        int rc = ensure_init();
-        if (rc) return rc;
-        int two_adicity = field == GH_MNT4753_FR ? GH_P6_TWO_ADICITY : GH_P4_TWO_ADICITY;
-        if ((int)log_n >= two_adicity) { g_err = "domain exceeds the field's 2-adicity"; return GH_E_UNSUPPORTED; }
-        rc = pool_get("fft_io", N * 96, &d);
-        if (rc) return rc;
-        size_t ncopy = n_in < N ? n_in : N;  // Vec::resize: truncate or zero-pad (domain.rs:121)
-        if (ncopy) HIPCHK(hipMemcpyAsync(d, in, ncopy * 96, hipMemcpyHostToDevice, g.stream));
-        if (ncopy < N) HIPCHK(hipMemsetAsync((char*)d + ncopy * 96, 0, (N - ncopy) * 96, g.stream));
-    }
-    int rc = gh_fft_dev(field, d, log_n, flags);
-    if (rc) return rc;
+    // ONE critical section: "fft_io" is a shared pool slot
     std::lock_guard<std::mutex> lk(g_mu);
+    int rc = ensure_init();
+    if (rc) return rc;
+    int two_adicity = field == GH_MNT4753_FR ? GH_P6_TWO_ADICITY : GH_P4_TWO_ADICITY;
+    if ((int)log_n >= two_adicity) { g_err = "domain exceeds the field's 2-adicity"; return GH_E_UNSUPPORTED; }
+    void* d = nullptr;
+    rc = pool_get("fft_io", N * 96, &d);
+    if (rc) return rc;
+    size_t ncopy = n_in < N ? n_in : N;  // Vec::resize: truncate or zero-pad (domain.rs:121)
+    if (ncopy) HIPCHK(hipMemcpyAsync(d, in, ncopy * 96, hipMemcpyHostToDevice, g.stream));
+    if (ncopy < N) HIPCHK(hipMemsetAsync((char*)d + ncopy * 96, 0, (N - ncopy) * 96, g.stream));
+    rc = fft_run(field, d, log_n, flags);
+    if (rc) return rc;
     HIPCHK(hipMemcpyAsync(out, d, N * 96, hipMemcpyDeviceToHost, g.stream));
     HIPCHK(hipStreamSynchronize(g.stream));
     return GH_OK;
@@ -482,6 +490,16 @@ int gh_dev_download(void* h_dst, const void* d_src, size_t bytes) {
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, g.stream));
     HIPCHK(hipStreamSynchronize(g.stream));
+    return GH_OK;
+}
+int gh_dev_trim(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g.ready) return GH_OK;
+    HIPCHK(hipStreamSynchronize(g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream_acc));
+    HIPCHK(hipStreamSynchronize(g.stream_red));
+    for (auto& kv : g.pool) if (kv.second.p) hipFree(kv.second.p);
+    g.pool.clear();
     return GH_OK;
 }
 int gh_dev_sync(void) {

@@ -302,6 +302,10 @@ struct MsmJob {
     uint32_t *counts = nullptr, *starts = nullptr, *cursor = nullptr, *sorted = nullptr, *order = nullptr, *size_hist = nullptr,
              *size_cursor = nullptr, *chunk_start = nullptr, *plan = nullptr;
     Proj<C>*buckets = nullptr, *seg_out = nullptr, *win_out = nullptr, *partials = nullptr;
+    // affine rounds (aff_kernels.h)
+    bool tree = false;
+    int tree_rounds = 0;
+    uint32_t *aff_cnt = nullptr, *aff_st = nullptr, *aff_nout = nullptr;
     uint32_t* hplan = nullptr;      // pinned
     Proj<C>* hw = nullptr;          // pinned, 9 RW points
     Aff<C>* salts = nullptr;
@@ -311,6 +315,15 @@ struct MsmJob {
     static int pinned(int slot, int which, size_t bytes, void** out) {
         static void* p[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
         static size_t cap[2][2] = {{0, 0}, {0, 0}};
+        static bool registered = false;
+        if (!registered) {   // gh_shutdown releases the staging buffers
+            registered = true;
+            g.at_shutdown.push_back([] {
+                for (auto& sl : p) for (auto& q : sl) { if (q) hipHostFree(q); q = nullptr; }
+                for (auto& sl : cap) for (auto& q : sl) q = 0;
+                registered = false;
+            });
+        }
         if (cap[slot][which] < bytes) {
             if (p[slot][which]) HIPCHK(hipHostFree(p[slot][which]));
             p[slot][which] = nullptr; cap[slot][which] = 0;
@@ -360,6 +373,13 @@ struct MsmJob {
             g_err = "MSM too large for 31-bit list entries";
             return GH_E_UNSUPPORTED;
         }
+        // Bucket sums by affine rounds (aff_kernels.h): g.affine_mode 0 = never, 1 = always, 2 = when the list is long
+        // enough to fill the chip (each round costs at least one inversion's latency, ~0.3 ms).
+        {
+            static const int env_aff = getenv("GH_AFFINE") ? atoi(getenv("GH_AFFINE")) : -1;
+            const int mode = env_aff >= 0 ? env_aff : g.affine_mode;
+            tree = C::F::DEG == 1 && (mode == 1 || (mode == 2 && (size_t)W * n >= ((size_t)1 << 21)));
+        }
         // salt points S0 = G, S1 = 2G (internal affine form) for the accumulate kernel's detour
         static Aff<C>* d_salts = nullptr;
         if (!d_salts) {
@@ -367,6 +387,7 @@ struct MsmJob {
             if (int src = make_salts<C>(hs)) return src;
             HIPCHK(hipMalloc((void**)&d_salts, sizeof(hs)));
             HIPCHK(hipMemcpy(d_salts, hs, sizeof(hs), hipMemcpyHostToDevice));
+            g.at_shutdown.push_back([] { if (d_salts) hipFree(d_salts); d_salts = nullptr; });
         }
         salts = d_salts;
         // Heavy threshold.  Buckets are walked longest first, one per thread at ~78 us per addition
@@ -397,12 +418,12 @@ struct MsmJob {
         POOL("size_hist", size_hist, MSM_SIZE_BINS * 4)
         POOL("size_cursor", size_cursor, MSM_SIZE_BINS * 4)
         POOL("chunk_start", chunk_start, (max_heavy + 2) * 4)
-        POOL("plan", plan, 16)
+        POOL("plan", plan, 64)
         POOL("buckets", buckets, slots * sizeof(Proj<C>))
         POOL("seg_out", seg_out, (size_t)RW * segs_per_window * 3 * sizeof(Proj<C>))
         POOL("win_out", win_out, (size_t)3 * RW * 3 * sizeof(Proj<C>))
 #undef POOL
-        if ((rc = pinned(slot, 0, 16, (void**)&hplan))) return rc;
+        if ((rc = pinned(slot, 0, 512, (void**)&hplan))) return rc;
         if ((rc = pinned(slot, 1, (size_t)9 * RW * sizeof(Proj<C>), (void**)&hw))) return rc;
         return GH_OK;
     }
@@ -417,12 +438,13 @@ struct MsmJob {
         HIPCHK(hipEventRecord(g.pev[slot][0], st));
         HIPCHK(hipMemsetAsync(counts, 0, total * 4, st));
         HIPCHK(hipMemsetAsync(size_hist, 0, MSM_SIZE_BINS * 4, st));
+        HIPCHK(hipMemsetAsync(plan, 0, 64, st));
         hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
                            (const uint32_t*)d_scalars, (const uint8_t*)h->d_inf, n, c, W, win_stride, top_unsigned, scalar_modulus<C>(), digits, counts, agg_iters);
         HIPCHK(hipGetLastError());
         if ((rc = device_scan(counts, starts, total, "scan_tmp"))) return rc;
         HIPCHK(hipMemcpyAsync(cursor, starts, total * 4, hipMemcpyDeviceToDevice, st));
-        hipLaunchKernelGGL(msm_size_hist_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, counts, total, heavy_thr, size_hist);
+        hipLaunchKernelGGL(msm_size_hist_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, counts, total, heavy_thr, size_hist, plan + 4);
         if ((rc = device_scan(size_hist, size_cursor, MSM_SIZE_BINS, "scan_tmp2"))) return rc;
         hipLaunchKernelGGL(msm_size_scatter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, counts, total, heavy_thr, size_cursor, order);
         hipLaunchKernelGGL(msm_heavy_plan_kernel, dim3(1), dim3(1), 0, st, (const uint32_t*)size_hist, (const uint32_t*)counts,
@@ -430,7 +452,7 @@ struct MsmJob {
         hipLaunchKernelGGL(msm_scatter_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)W), dim3(256), 0, st,
                            (const int32_t*)digits, n, W, win_stride, merged ? (uint32_t)h->n : 0u, cursor, sorted, agg_iters);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(hplan, plan, 16, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(hplan, plan, 32, hipMemcpyDeviceToHost, st));
         HIPCHK(hipEventRecord(g.pev[slot][1], st));
         return GH_OK;
     }
@@ -454,96 +476,10 @@ struct MsmJob {
         if (slots > total)   // padding slots of the last pseudo-window: infinity (Z = 0)
             HIPCHK(hipMemsetAsync((void*)(buckets + total), 0, (slots - total) * sizeof(Proj<C>), st));
         HIPCHK(hipEventRecord(g.pev[slot][2], st));
-        // G1 on a shift table: bucket sums in affine coordinates (msm_kernels.h 4c), the projective kernel
-        // only for the chunks of heavy buckets and for the buckets the affine kernel flags.
-        // Opt-in (gh_msm_set_affine / GH_AFFINE=1): correct and tested, but at 2^20 pairs it takes 27.6 ms against
-        // 22.6 ms for the projective kernel -- 20 % fewer VALU instructions, yet the VALU pipe is busy only 57 %
-        // of the time (projective: 82 %); see DESIGN.md section 4 for the counters.
-        static const bool affine_env = getenv("GH_AFFINE") != nullptr && atoi(getenv("GH_AFFINE")) != 0;
-        static const bool affine_env2 = getenv("GH_AFFINE") != nullptr && atoi(getenv("GH_AFFINE")) == 2;
-        bool affine = false;
-        if constexpr (C::F::DEG == 1) affine = merged && (affine_env || g.affine_mode != 0);
-        static const bool affine_env3 = getenv("GH_AFFINE") != nullptr && atoi(getenv("GH_AFFINE")) == 3;
-        if (affine && (g.affine_mode == 3 || affine_env3)) {
-            if constexpr (C::F::DEG == 1) {   // 4e: one bucket per lane, its pairs in affine
-                const uint32_t n_entries = hplan[2];
-                Fp* prefix;
-                uint32_t *flags, *flist, *fcount;
-                if ((rc = pool_get("aff_prefix", ((size_t)n_entries / 2 + total + 8) * sizeof(Fp), (void**)&prefix))) return rc;
-                if ((rc = pool_get("aff_flags", total * 4, (void**)&flags))) return rc;
-                if ((rc = pool_get("aff_flist", total * 4, (void**)&flist))) return rc;
-                if ((rc = pool_get("aff_fcount", 16, (void**)&fcount))) return rc;
-                HIPCHK(hipMemsetAsync(flags, 0, total * 4, st));
-                HIPCHK(hipMemsetAsync(fcount, 0, 16, st));
-                if (n_chunks > 0)   // chunks of the heavy buckets stay projective
-                    hipLaunchKernelGGL((msm_accumulate_kernel<C, 2>), dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, st,
-                                       (const Aff<C>*)src_points, (const uint32_t*)sorted, (const uint32_t*)starts,
-                                       (const uint32_t*)counts, (const uint32_t*)order, n_heavy, (const Aff<C>*)salts, buckets,
-                                       (const uint32_t*)chunk_start, n_heavy, n_chunks, heavy_chunk, partials, (const uint32_t*)nullptr);
-                hipLaunchKernelGGL((msm_accumulate_pair_kernel<C>), dim3((unsigned)((total - n_heavy + 255) / 256)), dim3(256), 0, st,
-                                   (const Aff<C>*)src_points, (const uint32_t*)sorted, (const uint32_t*)starts, (const uint32_t*)counts,
-                                   (const uint32_t*)order, n_heavy, (uint32_t)total, prefix, flags, buckets);
-                hipLaunchKernelGGL(msm_collect_flagged_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
-                                   (const uint32_t*)flags, (uint32_t)total, flist, fcount);
-                hipLaunchKernelGGL((msm_accumulate_kernel<C, 2>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
-                                   (const Aff<C>*)src_points, (const uint32_t*)sorted, (const uint32_t*)starts,
-                                   (const uint32_t*)counts, (const uint32_t*)flist, 0u, (const Aff<C>*)salts, buckets,
-                                   (const uint32_t*)chunk_start, 0u, 0u, heavy_chunk, partials, (const uint32_t*)fcount);
-            }
-        } else if (affine) {
-            if constexpr (C::F::DEG == 1) {
-                const uint32_t n_entries = hplan[2];
-                uint32_t n_lanes = (uint32_t)g.num_cus * 512u;              // 2 blocks of 256 per CU
-                uint32_t T = (n_entries + n_lanes - 1) / n_lanes;
-                if (T < 64) T = 64;
-                if (T > 512) T = 512;
-                {   // small inputs: no more lanes (and private scratch) than there are slices
-                    const uint32_t items = (n_entries + T - 1) / T + 1;
-                    const uint32_t need = (items + 255u) / 256u * 256u;
-                    if (need < n_lanes) n_lanes = need;
-                }
-                const uint32_t aff_thr = heavy_thr < 256 ? heavy_thr : 256;
-                AffTreeArgs<C> a;
-                a.table = (const Aff<C>*)src_points; a.sorted = sorted; a.starts = starts; a.counts = counts;
-                a.total = (uint32_t)total; a.n_entries = n_entries; a.T = T; a.n_items = (n_entries + T - 1) / T;
-                if (a.n_items == 0) a.n_items = 1;
-                a.n_lanes = n_lanes; a.aff_thr = aff_thr; a.heavy_thr = heavy_thr; a.cap = T + aff_thr + 8;
-                uint32_t *flags, *flist, *fcount;
-                const bool pair_mode = g.affine_mode == 2 || affine_env2;     // 4d: no point buffers, running products only
-                if ((rc = pool_get("aff_bufA", pair_mode ? 256 : (size_t)n_lanes * a.cap * sizeof(Aff<C>), (void**)&a.bufA))) return rc;
-                if ((rc = pool_get("aff_bufB", pair_mode ? 256 : (size_t)n_lanes * a.cap * sizeof(Aff<C>), (void**)&a.bufB))) return rc;
-                if ((rc = pool_get("aff_prefix", (size_t)n_lanes * (a.cap / 2 + 2) * sizeof(Fp), (void**)&a.prefix))) return rc;
-                if ((rc = pool_get("aff_desc", (size_t)n_lanes * (a.cap / 2 + 2) * sizeof(uint4), (void**)&a.desc))) return rc;
-                if ((rc = pool_get("aff_flags", total * 4, (void**)&flags))) return rc;
-                if ((rc = pool_get("aff_flist", total * 4, (void**)&flist))) return rc;
-                if ((rc = pool_get("aff_fcount", 16, (void**)&fcount))) return rc;
-                a.flags = flags; a.buckets = buckets; a.work = fcount + 1;
-                if (pair_mode) {   // 4d hands slices out dynamically: more, shorter slices than lanes
-                    static const int env_T = getenv("GH_PAIR_T") ? atoi(getenv("GH_PAIR_T")) : 0;
-                    a.T = env_T > 0 ? (uint32_t)env_T : (T > 128 ? T / 2 : T);
-                    a.n_items = (n_entries + a.T - 1) / a.T;
-                    if (a.n_items == 0) a.n_items = 1;
-                }
-                HIPCHK(hipMemsetAsync(flags, 0, total * 4, st));
-                HIPCHK(hipMemsetAsync(fcount, 0, 16, st));
-                if (n_chunks > 0)   // chunks of the heavy buckets only (total := n_heavy leaves no whole-bucket task)
-                    hipLaunchKernelGGL((msm_accumulate_kernel<C, 2>), dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, st,
-                                       (const Aff<C>*)src_points, (const uint32_t*)sorted, (const uint32_t*)starts,
-                                       (const uint32_t*)counts, (const uint32_t*)order, n_heavy, (const Aff<C>*)salts, buckets,
-                                       (const uint32_t*)chunk_start, n_heavy, n_chunks, heavy_chunk, partials, (const uint32_t*)nullptr);
-                if (g.affine_mode == 2 || affine_env2)
-                    hipLaunchKernelGGL((msm_pair_madd_kernel<C>), dim3(n_lanes / 256), dim3(256), 0, st, a);
-                else
-                    hipLaunchKernelGGL((msm_affine_tree_kernel<C>), dim3(n_lanes / 256), dim3(256), 0, st, a);
-                hipLaunchKernelGGL(msm_collect_flagged_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
-                                   (const uint32_t*)flags, (uint32_t)total, flist, fcount);
-                // flagged buckets (equal x in some addition, or longer than aff_thr): one projective task each
-                hipLaunchKernelGGL((msm_accumulate_kernel<C, 2>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
-                                   (const Aff<C>*)src_points, (const uint32_t*)sorted, (const uint32_t*)starts,
-                                   (const uint32_t*)counts, (const uint32_t*)flist, 0u, (const Aff<C>*)salts, buckets,
-                                   (const uint32_t*)chunk_start, 0u, 0u, heavy_chunk, partials, (const uint32_t*)fcount);
-            }
-        } else {
+        if (tree) {   // may clear `tree` when its scratch does not fit next to the key: the projective kernel takes over
+            if constexpr (C::F::DEG == 1) { if ((rc = launch_tree(st))) return rc; }
+        }
+        if (!tree) {
         {
             // one launch: the chunks of the heavy buckets first, then every other bucket, longest first
             const size_t tasks = (size_t)n_chunks + (total - n_heavy);
@@ -566,12 +502,12 @@ struct MsmJob {
                     hipLaunchKernelGGL((msm_accumulate_kernel<C, 2>), dim3((unsigned)((tasks + 255) / 256)), dim3(256), 0, st,
                                        (const Aff<C>*)src_points, (const uint32_t*)sorted, (const uint32_t*)starts,
                                        (const uint32_t*)counts, (const uint32_t*)order, (uint32_t)total, (const Aff<C>*)salts, buckets,
-                                       (const uint32_t*)chunk_start, n_heavy, n_chunks, heavy_chunk, partials, (const uint32_t*)nullptr);
+                                       (const uint32_t*)chunk_start, n_heavy, n_chunks, heavy_chunk, partials);
                 else
                     hipLaunchKernelGGL((msm_accumulate_kernel<C, 1>), dim3((unsigned)((tasks + 255) / 256)), dim3(256), 0, st,
                                        (const Aff<C>*)src_points, (const uint32_t*)sorted, (const uint32_t*)starts,
                                        (const uint32_t*)counts, (const uint32_t*)order, (uint32_t)total, (const Aff<C>*)salts, buckets,
-                                       (const uint32_t*)chunk_start, n_heavy, n_chunks, heavy_chunk, partials, (const uint32_t*)nullptr);
+                                       (const uint32_t*)chunk_start, n_heavy, n_chunks, heavy_chunk, partials);
             }
         }
         }
@@ -583,6 +519,96 @@ struct MsmJob {
             HIPCHK(hipGetLastError());
         }
         HIPCHK(hipEventRecord(g.pev[slot][4], st));
+        return GH_OK;
+    }
+
+    // Bucket sums by affine rounds (aff_kernels.h) on stream st: plan (per-round bucket sizes and offsets: R small
+    // scans), R rounds (descriptor kernel + round kernel), then the projective kernel over what is left per bucket.
+    int launch_tree(hipStream_t st) {
+        typedef F1S<typename C::PF> FS;
+        constexpr int LANES = FS::LANES;
+        constexpr uint32_t TPW = 64 / LANES;
+        int rc;
+        const uint32_t n0 = hplan[2], maxc = hplan[4];
+        static const int env_R = getenv("GH_AFF_ROUNDS") ? atoi(getenv("GH_AFF_ROUNDS")) : 0;
+        static const int env_bmin = getenv("GH_AFF_BMIN") ? atoi(getenv("GH_AFF_BMIN")) : 8;
+        static const int env_fin = getenv("GH_AFF_FINISH_MAX") ? atoi(getenv("GH_AFF_FINISH_MAX")) : 64;
+        // rounds: down to ~2 points per bucket on average, and no bucket left with more than env_fin points
+        int R = 1;
+        {
+            const double mean = (double)n0 / (double)(total > 1 ? total - 1 : 1);
+            while (R < AFF_MAX_ROUNDS && (double)(1u << (R + 1)) < mean) R++;
+            if (env_R > 0) R = env_R;
+            while (R < AFF_MAX_ROUNDS && (maxc >> R) > (uint32_t)env_fin) R++;
+        }
+        tree_rounds = R;
+        const size_t stride = (total + 63) & ~(size_t)63;
+        char nm[48];
+#define POOLT(name, ptr, bytes)                                     \
+    snprintf(nm, sizeof nm, "%s#%d", name, slot);                   \
+    if ((rc = pool_get(nm, bytes, (void**)&ptr))) return rc;
+        POOLT("aff_cnt", aff_cnt, (size_t)R * stride * 4)
+        POOLT("aff_st", aff_st, (size_t)R * stride * 4)
+        POOLT("aff_nout", aff_nout, (AFF_MAX_ROUNDS + 2) * 4)
+        hipLaunchKernelGGL(aff_counts_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                           (const uint32_t*)counts, (uint32_t)total, R, stride, aff_cnt);
+        snprintf(nm, sizeof nm, "aff_scan#%d", slot);
+        for (int r = 1; r <= R; r++)
+            if ((rc = device_scan(aff_cnt + (size_t)(r - 1) * stride, aff_st + (size_t)(r - 1) * stride, total, nm, st))) return rc;
+        hipLaunchKernelGGL(aff_totals_kernel, dim3(1), dim3(64), 0, st, (const uint32_t*)starts, (const uint32_t*)counts,
+                           (const uint32_t*)aff_st, (const uint32_t*)aff_cnt, (uint32_t)total, R, stride, aff_nout);
+        HIPCHK(hipGetLastError());
+        uint32_t* hn = hplan + 16;   // n_0 .. n_R
+        HIPCHK(hipMemcpyAsync(hn, aff_nout, (size_t)(R + 1) * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (hn[0] != n0) { g_err = "internal: affine plan disagrees with the sort stage"; return GH_E_HIP; }
+        size_t n_desc = 0;
+        for (int r = 1; r <= R; r++) n_desc += hn[r];
+        uint32_t* desc;
+        Aff<C>*ptsA, *ptsB;
+        Fp* prefix;
+#undef POOLT
+#define POOLBIG(name, ptr, bytes)                                   \
+    snprintf(nm, sizeof nm, "%s#%d", name, slot);                   \
+    rc = pool_get(nm, bytes, (void**)&ptr);                         \
+    if (rc == GH_E_NOMEM) { (void)hipGetLastError(); tree = false; return GH_OK; } \
+    if (rc) return rc;
+        POOLBIG("aff_desc", desc, (n_desc + 64) * 4)
+        POOLBIG("aff_ptsA", ptsA, ((size_t)hn[1] + 64) * sizeof(Aff<C>))
+        POOLBIG("aff_ptsB", ptsB, ((size_t)(R >= 2 ? hn[2] : 0) + 64) * sizeof(Aff<C>))
+        POOLBIG("aff_prefix", prefix, ((size_t)hn[1] + 64) * LANES * sizeof(Fp))
+#undef POOLBIG
+        const uint32_t max_waves = (uint32_t)g.num_cus * 4u * (uint32_t)FS::WAVES;
+        size_t doff = 0;
+        const Aff<C>* in = (const Aff<C>*)(merged ? h->d_table : h->d_points);
+        for (int r = 0; r < R; r++) {
+            const uint32_t n_out = hn[r + 1];
+            Aff<C>* out = (r & 1) ? ptsB : ptsA;
+            if (n_out > 0) {
+                const uint32_t* st_in = r == 0 ? starts : aff_st + (size_t)(r - 1) * stride;
+                const uint32_t* m_in = r == 0 ? counts : aff_cnt + (size_t)(r - 1) * stride;
+                unsigned dgrid = (n_out + 255) / 256;
+                if (dgrid > 16384) dgrid = 16384;
+                hipLaunchKernelGGL(aff_desc_kernel, dim3(dgrid), dim3(256), 0, st, st_in, m_in,
+                                   (const uint32_t*)(aff_st + (size_t)r * stride), (uint32_t)total,
+                                   (const uint32_t*)(aff_nout + r + 1), desc + doff);
+                uint32_t waves = (n_out + TPW * (uint32_t)env_bmin - 1) / (TPW * (uint32_t)env_bmin);
+                if (waves > max_waves) waves = max_waves;
+                waves = (waves + 3u) & ~3u;
+                AffRoundArgs<C> a;
+                a.in = in; a.sorted = r == 0 ? sorted : nullptr; a.desc = desc + doff; a.n_out_p = aff_nout + r + 1;
+                a.prefix = prefix; a.out = out; a.groups = waves * TPW; a.bmin = (uint32_t)env_bmin;
+                hipLaunchKernelGGL((aff_round_kernel<C, FS>), dim3(waves / 4), dim3(256), 0, st, a);
+            }
+            doff += n_out;
+            in = out;
+        }
+        // what is left (about two points per bucket): projective, one bucket per thread, longest first
+        hipLaunchKernelGGL((msm_accumulate_kernel<C, 2, true>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, in,
+                           (const uint32_t*)nullptr, (const uint32_t*)(aff_st + (size_t)(R - 1) * stride),
+                           (const uint32_t*)(aff_cnt + (size_t)(R - 1) * stride), (const uint32_t*)order, (uint32_t)total,
+                           (const Aff<C>*)salts, buckets, (const uint32_t*)chunk_start, 0u, 0u, heavy_chunk, (Proj<C>*)nullptr);
+        n_heavy = 0;   // no chunk sums to combine
         return GH_OK;
     }
 

@@ -28,6 +28,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "ec29.h"
+#include "aff_kernels.h"
 
 namespace gh {
 
@@ -325,14 +326,21 @@ static __device__ __forceinline__ uint32_t msm_size_bin(uint32_t cnt, uint32_t h
     return heavy_thr + 1 - bin;  // reversed: heavy -> 0, then sizes heavy_thr .. 0
 }
 static __global__ void __launch_bounds__(256)
-msm_size_hist_kernel(const uint32_t* counts, size_t total, uint32_t heavy_thr, uint32_t* size_hist) {
+msm_size_hist_kernel(const uint32_t* counts, size_t total, uint32_t heavy_thr, uint32_t* size_hist, uint32_t* max_count) {
     __shared__ uint32_t h[MSM_SIZE_BINS];
+    __shared__ uint32_t bmax;
     for (int i = threadIdx.x; i < MSM_SIZE_BINS; i += 256) h[i] = 0;
+    if (threadIdx.x == 0) bmax = 0;
     __syncthreads();
     size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g < total) atomicAdd(&h[msm_size_bin(counts[g], heavy_thr)], 1u);
+    if (g < total) {
+        const uint32_t c = counts[g];
+        atomicAdd(&h[msm_size_bin(c, heavy_thr)], 1u);
+        atomicMax(&bmax, c);      // the largest bucket (the affine rounds size their depth by it)
+    }
     __syncthreads();
     for (int i = threadIdx.x; i < MSM_SIZE_BINS; i += 256) if (h[i]) atomicAdd(&size_hist[i], h[i]);
+    if (threadIdx.x == 0 && bmax) atomicMax(max_count, bmax);
 }
 static __global__ void __launch_bounds__(256)
 msm_size_scatter_kernel(const uint32_t* counts, size_t total, uint32_t heavy_thr, uint32_t* size_cursor, uint32_t* order) {
@@ -392,19 +400,19 @@ msm_scatter_kernel(const int32_t* __restrict__ digits, size_t n, int num_windows
 //
 // WAVES = minimum waves per SIMD the register allocation must allow (1: up to 512 VGPR+AGPR,
 // 2: up to 256); selected at run time (GH_ACC_WAVES) for A/B measurements.
-template <class C, int WAVES>
+// AFFIN = true: the input is the output list of the affine rounds (aff_kernels.h): bucket g owns the records
+// [starts[g], starts[g] + counts[g]) of `bases` directly (no index list, no signs) and infinity markers are skipped.
+template <class C, int WAVES, bool AFFIN = false>
 __global__ void __launch_bounds__(256, WAVES)
 msm_accumulate_kernel(const Aff<C>* __restrict__ bases, const uint32_t* __restrict__ sorted,
                       const uint32_t* __restrict__ starts, const uint32_t* __restrict__ counts,
                       const uint32_t* __restrict__ order, uint32_t total,
                       const Aff<C>* __restrict__ salts, Proj<C>* __restrict__ buckets,
                       const uint32_t* __restrict__ chunk_start, uint32_t n_heavy, uint32_t n_chunks, uint32_t chunk,
-                      Proj<C>* __restrict__ partials, const uint32_t* __restrict__ dyn_total) {
+                      Proj<C>* __restrict__ partials) {
     typedef typename C::F F;
     // task list: [0, n_chunks) chunks of the heavy buckets (the longest tasks, scheduled first),
     //            then the buckets order[n_heavy ..] by descending size
-    // (dyn_total: the list length lives in device memory -- the fallback list of the affine path)
-    if (dyn_total != nullptr) total = *dyn_total;
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_chunks + (total - n_heavy)) return;
     uint32_t beg, cnt;
@@ -439,9 +447,14 @@ msm_accumulate_kernel(const Aff<C>* __restrict__ bases, const uint32_t* __restri
             q = ld_aff<C>(salts + salt_id);
             if (phase == 3) q.y = F::neg(q.y);
         } else {
-            const uint32_t e = sorted[beg + k];
-            q = ld_aff<C>(bases + (e & 0x7FFFFFFFu));
-            if (e >> 31) q.y = F::neg(q.y);
+            if constexpr (AFFIN) {
+                q = ld_aff<C>(bases + beg + k);
+                if (phase == 0 && F::comp(q.x, 0).l[0] == AFF_MARK) { k++; continue; }   // a cancelled pair: nothing to add
+            } else {
+                const uint32_t e = sorted[beg + k];
+                q = ld_aff<C>(bases + (e & 0x7FFFFFFFu));
+                if (e >> 31) q.y = F::neg(q.y);
+            }
         }
         if (proj_is_zero<C>(acc)) {
             acc.x = q.x; acc.y = q.y; acc.z = F::one();
@@ -737,419 +750,6 @@ msm_accumulate_split_kernel(const Aff<C>* __restrict__ bases, const uint32_t* __
         st_fp(o + 1 * LANES + comp, ay);
         st_fp(o + 2 * LANES + comp, az);
     }
-}
-
-// ---------------------------------------------------------------- 4c. bucket sums in AFFINE coordinates
-// With one bucket set (shift table) a bucket sum is a sum of ~36 table points in any order.  In
-// affine coordinates an addition costs 1 inversion + 2 M + 1 S; Montgomery's trick turns the
-// inversions of G independent additions into ONE inversion + 3 (G - 1) M, and the safegcd inversion
-// (fp29.h fp_inv) costs about 40 M -- so an addition comes to ~6 M + 40/G against the 11 M of the
-// projective mixed addition.  Independent additions come from pairing: round r adds the points of a
-// bucket two by two (c -> ceil(c / 2) points), ~log2(c) rounds.
-//
-// One lane owns the whole buckets whose lists start inside its slice of T list entries (~8 buckets,
-// ~288 entries at 2^20 pairs) and runs every round privately: forward pass (denominators x2 - x1,
-// running products parked in its scratch), one inversion, backward pass (lambda, x3, y3 into the
-// other of two private point buffers).  No cross-lane step, no atomics.  288 GB of HBM pay for
-// the private scratch (~0.2 MB per resident lane).
-//
-// Not handled here, by design: x2 == x1 (P + P, P - P) -- the denominator is replaced by 1 so the
-// batch stays invertible, the bucket is flagged, and the flagged buckets are summed again by the
-// projective kernel above (detour through the salt point) after this launch; buckets longer than
-// aff_thr are flagged up front; buckets longer than heavy_thr are the chunked ones (left alone).
-template <class C> __device__ __forceinline__ Aff<C> ld_aff16(const Aff<C>* p) {   // 16-byte loads (records are 16-byte aligned)
-    static_assert(sizeof(Aff<C>) % 16 == 0, "Aff must be a multiple of 16 bytes");
-    Aff<C> r;
-    const uint4* q = reinterpret_cast<const uint4*>(p);
-    uint4* d = reinterpret_cast<uint4*>(&r);
-#pragma unroll
-    for (int i = 0; i < (int)(sizeof(Aff<C>) / 16); i++) d[i] = q[i];
-    return r;
-}
-template <class C> __device__ __forceinline__ void st_aff16(Aff<C>* p, const Aff<C>& v) {
-    uint4* q = reinterpret_cast<uint4*>(p);
-    const uint4* s = reinterpret_cast<const uint4*>(&v);
-#pragma unroll
-    for (int i = 0; i < (int)(sizeof(Aff<C>) / 16); i++) q[i] = s[i];
-}
-template <class C> struct AffTreeArgs {
-    const Aff<C>* table;
-    const uint32_t *sorted, *starts, *counts;
-    uint32_t total;              // bucket slots
-    uint32_t n_entries, T, n_items, n_lanes;
-    uint32_t aff_thr, heavy_thr, cap;
-    Aff<C>*bufA, *bufB;          // n_lanes x cap points each
-    Fp* prefix;                  // n_lanes x (cap / 2 + 2)
-    uint4* desc;                 // n_lanes x (cap / 2 + 2): (index of the pair's first input, output index, bucket, -)
-    uint32_t* flags;             // per bucket
-    uint32_t* work;              // 4d: next unclaimed slice
-    Proj<C>* buckets;
-};
-
-static __device__ __forceinline__ uint32_t first_bucket_at(const uint32_t* starts, uint32_t total, uint32_t e) {
-    uint32_t lo = 0, hi = total;   // first b with starts[b] >= e  (starts is non-decreasing)
-    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (starts[mid] < e) lo = mid + 1; else hi = mid; }
-    return lo;
-}
-
-template <class C>
-__global__ void __launch_bounds__(256, 2) msm_affine_tree_kernel(AffTreeArgs<C> a) {
-    typedef typename C::F F;
-    typedef typename F::T FT;
-    static_assert(F::DEG == 1, "affine tree kernel: prime-field curves");
-    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= a.n_lanes) return;
-    // Private scratch, interleaved by lane inside a wave: slot s of lane l sits at (s * 64 + l).  The lanes of
-    // a wave walk their slots nearly in step, so one wave-wide access stays within a few KB (one TLB
-    // fragment, shared cache lines) instead of 64 regions 90 KB apart.
-    const size_t wv = gid >> 6, ln = gid & 63u;
-    Aff<C>* const bufA = a.bufA + wv * a.cap * 64 + ln;
-    Aff<C>* const bufB = a.bufB + wv * a.cap * 64 + ln;
-    Fp* const pre = a.prefix + wv * (a.cap / 2 + 2) * 64 + ln;
-    uint4* const desc = a.desc + wv * (a.cap / 2 + 2) * 64 + ln;
-    auto count_of = [&](uint32_t b) -> uint32_t {   // entries this kernel sums for bucket b
-        const uint32_t c = a.counts[b];
-        return c > a.aff_thr ? 0u : c;
-    };
-    auto load_pt = [&](int r, const Aff<C>* in, uint32_t idx) -> Aff<C> {
-        if (r == 0) {
-            const uint32_t e = a.sorted[idx];
-            Aff<C> q = ld_aff16<C>(a.table + (e & 0x7FFFFFFFu));
-            if (e >> 31) q.y = F::neg(q.y);
-            return q;
-        }
-        return ld_aff16<C>(in + (size_t)idx * 64);
-    };
-    for (uint32_t item = gid; item < a.n_items; item += a.n_lanes) {
-        const uint32_t e0 = item * a.T;
-        const uint32_t b0 = first_bucket_at(a.starts, a.total, e0);
-        const uint32_t b1 = item + 1 == a.n_items ? a.total : first_bucket_at(a.starts, a.total, e0 + a.T);
-        uint32_t maxc = 0;
-        for (uint32_t b = b0; b < b1; b++) {
-            const uint32_t c = a.counts[b];
-            if (c > a.aff_thr && c <= a.heavy_thr) a.flags[b] = 1u;   // too long for the private buffers: projective fallback
-            const uint32_t ce = c > a.aff_thr ? 0u : c;
-            maxc = ce > maxc ? ce : maxc;
-        }
-        const int R = maxc <= 1 ? 0 : 32 - __clz((int)(maxc - 1));
-        for (int r = 0; r < R; r++) {
-            const Aff<C>* in = (r & 1) ? bufA : bufB;      // r = 0 reads the lists; r = 1 reads A, writes B; r = 2 reads B ...
-            Aff<C>* out = (r & 1) ? bufB : bufA;
-            // ---- descriptors (no field arithmetic): one (first input, output, bucket) triple per addition of
-            //      this round, bucket by bucket; odd leftovers are copied to their output slot
-            uint32_t np = 0, pos = 0, outpos = 0;
-            for (uint32_t b = b0; b < b1; b++) {
-                const uint32_t c0 = count_of(b);
-                const uint32_t cr = (c0 + (1u << r) - 1u) >> r;
-                const uint32_t base = r == 0 ? a.starts[b] : pos;
-                const uint32_t half = cr >> 1;
-                for (uint32_t j = 0; j < half; j++) desc[(size_t)(np + j) * 64] = make_uint4(base + 2 * j, outpos + j, b, 0u);
-                np += half;
-                if (cr & 1u) st_aff16<C>(out + (size_t)(outpos + half) * 64, load_pt(r, in, base + cr - 1));
-                pos += cr;
-                outpos += half + (cr & 1u);
-            }
-            if (np == 0) continue;
-            // source of element idx: round 0 -> table row of list entry idx (sign in bit 31), later -> in[idx]
-            auto src_of = [&](uint32_t idx) -> uint32_t { return r == 0 ? a.sorted[idx] : idx; };
-            auto x_at = [&](uint32_t src) -> FT {
-                const Aff<C>* p = r == 0 ? a.table + (src & 0x7FFFFFFFu) : in + (size_t)src * 64;
-                return ld_fp(reinterpret_cast<const Fp*>(p));
-            };
-            auto pt_at = [&](uint32_t src) -> Aff<C> {
-                if (r == 0) {
-                    Aff<C> q = ld_aff16<C>(a.table + (src & 0x7FFFFFFFu));
-                    if (src >> 31) q.y = F::neg(q.y);
-                    return q;
-                }
-                return ld_aff16<C>(in + (size_t)src * 64);
-            };
-            // ---- forward: denominators x2 - x1 and their running products (sources of the next pair are
-            //      fetched one iteration ahead: desc -> list entry -> table row is a chain of dependent loads)
-            FT acc = F::one();
-            {
-                uint4 de = desc[0];
-                uint32_t s1 = src_of(de.x), s2 = src_of(de.x + 1);
-                for (uint32_t k = 0; k < np; k++) {
-                    const uint32_t bk = de.z;
-                    const FT x1 = x_at(s1), x2 = x_at(s2);
-                    if (k + 1 < np) { de = desc[(size_t)(k + 1) * 64]; s1 = src_of(de.x); s2 = src_of(de.x + 1); }
-                    FT d = F::sub(x2, x1);
-                    if (F::is_zero(d)) { a.flags[bk] = 1u; d = F::one(); }
-                    acc = F::mul(acc, d);
-                    st_fp(pre + (size_t)k * 64, acc);
-                }
-            }
-            // ---- one inversion for all additions of this round
-            FT inv = fp_inv<typename C::PF>(acc);
-            // ---- backward: 1 / (x2 - x1) per pair, lambda, the sum
-            {
-                uint4 de = desc[(size_t)(np - 1) * 64];
-                uint32_t s1 = src_of(de.x), s2 = src_of(de.x + 1);
-                for (uint32_t k = np; k-- > 0;) {
-                    const uint32_t oidx = de.y;
-                    const Aff<C> p1 = pt_at(s1), p2 = pt_at(s2);
-                    if (k > 0) { de = desc[(size_t)(k - 1) * 64]; s1 = src_of(de.x); s2 = src_of(de.x + 1); }
-                    FT d = F::sub(p2.x, p1.x);
-                    if (F::is_zero(d)) d = F::one();
-                    FT dinv = inv;
-                    if (k > 0) dinv = F::mul(inv, ld_fp(pre + (size_t)(k - 1) * 64));
-                    inv = F::mul(inv, d);
-                    const FT lam = F::mul(F::sub(p2.y, p1.y), dinv);
-                    Aff<C> s3;
-                    s3.x = F::sub(F::sub(F::sqr(lam), p1.x), p2.x);
-                    s3.y = F::sub(F::mul(lam, F::sub(p1.x, s3.x)), p1.y);
-                    st_aff16<C>(out + (size_t)oidx * 64, s3);
-                }
-            }
-        }
-        // ---- results: one point per non-empty bucket, in bucket order, in the last round's output
-        const Aff<C>* fin = R == 0 ? nullptr : (((R - 1) & 1) ? bufB : bufA);
-        uint32_t pos = 0;
-        for (uint32_t b = b0; b < b1; b++) {
-            const uint32_t c = a.counts[b];
-            if (c > a.aff_thr) continue;                    // chunked (heavy) or flagged for the fallback
-            Proj<C> o;
-            if (c == 0) {
-                o = proj_zero<C>();
-            } else {
-                const Aff<C> q = R == 0 ? load_pt(0, nullptr, a.starts[b]) : ld_aff16<C>(fin + (size_t)pos * 64);
-                o.x = q.x; o.y = q.y; o.z = F::one();
-                pos++;
-            }
-            st_proj<C>(a.buckets + b, o);
-        }
-    }
-}
-
-// ---------------------------------------------------------------- 4d. pairs in affine, pairs into the bucket projectively
-// One affine round only, consumed on the fly: the list entries of a bucket are taken two by two, the pair sum
-// S = P + Q is formed in affine coordinates (its inversion shared by all pairs of the lane: forward pass of
-// running products over x2 - x1, ONE safegcd inversion, backward pass), and S goes straight into the bucket's
-// projective accumulator by a mixed addition.  Per two entries: 1 + 5 + 11 = 17 products instead of 22; no
-// intermediate point is ever written (scratch: the running products only, 52 B per entry), one inversion per
-// ~144 pairs.  Same ownership as 4c (a lane owns the buckets of a slice of T list entries), same flags:
-// equal x in a pair, the accumulator meeting its own value, buckets longer than aff_thr -> projective fallback.
-template <class C>
-__global__ void __launch_bounds__(256, 2) msm_pair_madd_kernel(AffTreeArgs<C> a) {
-    typedef typename C::F F;
-    typedef typename F::T FT;
-    static_assert(F::DEG == 1, "pair kernel: prime-field curves");
-    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= a.n_lanes) return;
-    const size_t wv = gid >> 6, ln = gid & 63u;
-    Fp* const pre = a.prefix + wv * (a.cap / 2 + 2) * 64 + ln;      // lane-interleaved, as in 4c
-    __shared__ uint32_t park[NL][256];
-    auto pt_of = [&](uint32_t e) -> Aff<C> {
-        Aff<C> q = ld_aff16<C>(a.table + (e & 0x7FFFFFFFu));
-        if (e >> 31) q.y = F::neg(q.y);
-        return q;
-    };
-    auto x_of = [&](uint32_t e) -> FT { return ld_fp(reinterpret_cast<const Fp*>(a.table + (e & 0x7FFFFFFFu))); };
-    // slices are handed out dynamically, 64 at a time per wave (a.work: device counter, zeroed by the host):
-    // waves that finish early take more
-    for (;;) {
-        uint32_t first = 0;
-        if (ln == 0) first = atomicAdd(a.work, 64u);
-        first = (uint32_t)__shfl((int)first, 0);
-        if (first >= a.n_items) break;
-        const uint32_t item = first + (uint32_t)ln;
-        if (item >= a.n_items) continue;
-        const uint32_t e0 = item * a.T;
-        const uint32_t b0 = first_bucket_at(a.starts, a.total, e0);
-        const uint32_t b1 = item + 1 == a.n_items ? a.total : first_bucket_at(a.starts, a.total, e0 + a.T);
-        // ---- forward: x2 - x1 of every pair, running products
-        FT acc = F::one();
-        uint32_t np = 0;
-        for (uint32_t b = b0; b < b1; b++) {
-            const uint32_t c = a.counts[b];
-            if (c > a.aff_thr) { if (c <= a.heavy_thr) a.flags[b] = 1u; continue; }
-            const uint32_t base = a.starts[b], half = c >> 1;
-            for (uint32_t j = 0; j < half; j++) {
-                FT d = F::sub(x_of(a.sorted[base + 2 * j + 1]), x_of(a.sorted[base + 2 * j]));
-                if (F::is_zero(d)) { a.flags[b] = 1u; d = F::one(); }
-                acc = F::mul(acc, d);
-                st_fp(pre + (size_t)np * 64, acc);
-                np++;
-            }
-        }
-        FT inv = F::one();
-        if (np > 0) inv = fp_inv<typename C::PF>(acc);
-        // ---- backward: buckets last to first, pairs last to first; pair sum in affine, then one mixed addition.
-        //      ONE flat loop over the lane's pairs with a bucket cursor: with a loop per bucket the 64 lanes of a wave
-        //      wait for the longest bucket at every bucket position (measured: 39 ms instead of 23 ms).
-        uint32_t k = np, b = b1, j = 0, base = 0;
-        bool open = false;                       // P holds the running sum of bucket b
-        Proj<C> P = proj_zero<C>();
-        auto step_bucket = [&]() {               // close bucket b, open the one below it
-            if (open) st_proj<C>(a.buckets + b, P);
-            b--;
-            const uint32_t c = a.counts[b];
-            open = c <= a.aff_thr;
-            j = 0;
-            if (!open) return;
-            base = a.starts[b];
-            j = c >> 1;
-            P = proj_zero<C>();
-            if (c & 1u) { const Aff<C> q = pt_of(a.sorted[base + c - 1]); P.x = q.x; P.y = q.y; P.z = F::one(); }
-        };
-        while (k > 0) {
-            while (j == 0) step_bucket();
-            j--;
-            k--;
-            const Aff<C> p1 = pt_of(a.sorted[base + 2 * j]), p2 = pt_of(a.sorted[base + 2 * j + 1]);
-            FT d = F::sub(p2.x, p1.x);
-            if (F::is_zero(d)) d = F::one();
-            FT dinv = inv;
-            if (k > 0) dinv = F::mul(inv, ld_fp(pre + (size_t)(k - 1) * 64));
-            inv = F::mul(inv, d);
-            const FT lam = F::mul(F::sub(p2.y, p1.y), dinv);
-            Aff<C> q;
-            q.x = F::sub(F::sub(F::sqr(lam), p1.x), p2.x);
-            q.y = F::sub(F::mul(lam, F::sub(p1.x, q.x)), p1.y);
-            if (proj_is_zero<C>(P)) {
-                P.x = q.x; P.y = q.y; P.z = F::one();
-            } else {   // madd-1998-cmo (swp.rs:497-517), operation order as in msm_accumulate_kernel
-                FT v = F::mul(q.x, P.z);
-                FT u = F::mul(q.y, P.z);
-                if (F::eq(u, P.y) && F::eq(v, P.x)) a.flags[b] = 1u;     // P == q: the fallback sums this bucket
-                u = F::sub(u, P.y);
-                v = F::sub(v, P.x);
-                {
-                    const uint32_t* yw = reinterpret_cast<const uint32_t*>(&P.y);
-#pragma unroll
-                    for (int w = 0; w < NL; w++) park[w][threadIdx.x] = yw[w];
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                FT vv = F::sqr(v);
-                __builtin_amdgcn_sched_barrier(0);
-                FT r = F::mul(vv, P.x);
-                __builtin_amdgcn_sched_barrier(0);
-                FT vvv = F::mul(v, vv);
-                __builtin_amdgcn_sched_barrier(0);
-                FT uu = F::sqr(u);
-                __builtin_amdgcn_sched_barrier(0);
-                FT aa = F::sub(F::sub(F::mul(uu, P.z), vvv), F::dbl(r));
-                __builtin_amdgcn_sched_barrier(0);
-                P.x = F::mul(v, aa);
-                __builtin_amdgcn_sched_barrier(0);
-                FT rma = F::sub(r, aa);
-                __builtin_amdgcn_sched_barrier(0);
-                FT y1;
-                {
-                    uint32_t* yw = reinterpret_cast<uint32_t*>(&y1);
-#pragma unroll
-                    for (int w = 0; w < NL; w++) yw[w] = park[w][threadIdx.x];
-                }
-                P.y = F::sub(F::mul(u, rma), F::mul(vvv, y1));
-                __builtin_amdgcn_sched_barrier(0);
-                P.z = F::mul(vvv, P.z);
-            }
-        }
-        while (b > b0) step_bucket();            // the buckets below the last pair: singles and empties
-        if (open) st_proj<C>(a.buckets + b, P);
-    }
-}
-
-// ---------------------------------------------------------------- 4e. the pair round, one bucket per lane
-// Same arithmetic as 4d, but with the task structure of msm_accumulate_kernel: one whole bucket per lane,
-// buckets walked longest first, so the lanes of a wave run the same number of pairs and never wait for each
-// other.  A lane's running products cover only its own bucket (~18 pairs at 2^20: the inversion costs ~2.4
-// products per pair), stored at prefix[(starts[g] >> 1) + j].  Chunks of heavy buckets stay with the
-// projective kernel; equal x in a pair / the accumulator meeting its own value flag the bucket for it.
-#ifndef GH_PAIR_WAVES
-#define GH_PAIR_WAVES 2
-#endif
-template <class C>
-__global__ void __launch_bounds__(256, GH_PAIR_WAVES)
-msm_accumulate_pair_kernel(const Aff<C>* __restrict__ table, const uint32_t* __restrict__ sorted,
-                           const uint32_t* __restrict__ starts, const uint32_t* __restrict__ counts,
-                           const uint32_t* __restrict__ order, uint32_t n_heavy, uint32_t total,
-                           Fp* __restrict__ prefix, uint32_t* __restrict__ flags, Proj<C>* __restrict__ buckets) {
-    typedef typename C::F F;
-    typedef typename F::T FT;
-    static_assert(F::DEG == 1, "pair kernel: prime-field curves");
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= total - n_heavy) return;
-    const uint32_t g = order[n_heavy + t];
-    const uint32_t beg = starts[g], cnt = counts[g], half = cnt >> 1;
-    Fp* const pre = prefix + (beg >> 1);
-    __shared__ uint32_t park[NL][256];
-    auto pt_of = [&](uint32_t e) -> Aff<C> {
-        Aff<C> q = ld_aff16<C>(table + (e & 0x7FFFFFFFu));
-        if (e >> 31) q.y = F::neg(q.y);
-        return q;
-    };
-    auto x_of = [&](uint32_t e) -> FT { return ld_fp(reinterpret_cast<const Fp*>(table + (e & 0x7FFFFFFFu))); };
-    FT acc = F::one();
-    for (uint32_t j = 0; j < half; j++) {
-        FT d = F::sub(x_of(sorted[beg + 2 * j + 1]), x_of(sorted[beg + 2 * j]));
-        if (F::is_zero(d)) { flags[g] = 1u; d = F::one(); }
-        acc = F::mul(acc, d);
-        st_fp(pre + j, acc);
-    }
-    FT inv = F::one();
-    if (half > 0) inv = fp_inv<typename C::PF>(acc);
-    Proj<C> P = proj_zero<C>();
-    if (cnt & 1u) { const Aff<C> q = pt_of(sorted[beg + cnt - 1]); P.x = q.x; P.y = q.y; P.z = F::one(); }
-    for (uint32_t j = half; j-- > 0;) {
-        const Aff<C> p1 = pt_of(sorted[beg + 2 * j]), p2 = pt_of(sorted[beg + 2 * j + 1]);
-        FT d = F::sub(p2.x, p1.x);
-        if (F::is_zero(d)) d = F::one();
-        FT dinv = inv;
-        if (j > 0) dinv = F::mul(inv, ld_fp(pre + j - 1));
-        inv = F::mul(inv, d);
-        const FT lam = F::mul(F::sub(p2.y, p1.y), dinv);
-        Aff<C> q;
-        q.x = F::sub(F::sub(F::sqr(lam), p1.x), p2.x);
-        q.y = F::sub(F::mul(lam, F::sub(p1.x, q.x)), p1.y);
-        if (proj_is_zero<C>(P)) {
-            P.x = q.x; P.y = q.y; P.z = F::one();
-        } else {   // madd-1998-cmo (swp.rs:497-517), operation order as in msm_accumulate_kernel
-            FT v = F::mul(q.x, P.z);
-            FT u = F::mul(q.y, P.z);
-            if (F::eq(u, P.y) && F::eq(v, P.x)) flags[g] = 1u;
-            u = F::sub(u, P.y);
-            v = F::sub(v, P.x);
-            {
-                const uint32_t* yw = reinterpret_cast<const uint32_t*>(&P.y);
-#pragma unroll
-                for (int w = 0; w < NL; w++) park[w][threadIdx.x] = yw[w];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            FT vv = F::sqr(v);
-            __builtin_amdgcn_sched_barrier(0);
-            FT r = F::mul(vv, P.x);
-            __builtin_amdgcn_sched_barrier(0);
-            FT vvv = F::mul(v, vv);
-            __builtin_amdgcn_sched_barrier(0);
-            FT uu = F::sqr(u);
-            __builtin_amdgcn_sched_barrier(0);
-            FT aa = F::sub(F::sub(F::mul(uu, P.z), vvv), F::dbl(r));
-            __builtin_amdgcn_sched_barrier(0);
-            P.x = F::mul(v, aa);
-            __builtin_amdgcn_sched_barrier(0);
-            FT rma = F::sub(r, aa);
-            __builtin_amdgcn_sched_barrier(0);
-            FT y1;
-            {
-                uint32_t* yw = reinterpret_cast<uint32_t*>(&y1);
-#pragma unroll
-                for (int w = 0; w < NL; w++) yw[w] = park[w][threadIdx.x];
-            }
-            P.y = F::sub(F::mul(u, rma), F::mul(vvv, y1));
-            __builtin_amdgcn_sched_barrier(0);
-            P.z = F::mul(vvv, P.z);
-        }
-    }
-    st_proj<C>(buckets + g, P);
-}
-
-// flagged buckets -> list for the projective kernel (dyn_total = n[0])
-static __global__ void __launch_bounds__(256)
-msm_collect_flagged_kernel(const uint32_t* __restrict__ flags, uint32_t total, uint32_t* __restrict__ list, uint32_t* __restrict__ n) {
-    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g < total && flags[g] != 0) list[atomicAdd(n, 1u)] = g;
 }
 
 // wave-level sum of one projective point per lane through LDS; result valid in lane 0.

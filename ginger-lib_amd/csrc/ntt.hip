@@ -30,34 +30,49 @@ template <class P> int build_pow_table(Fp* tab, int log_n, const Fp& first, Fp b
     return GH_OK;
 }
 
-template <class P> int get_domain(int fidx, int log_n, bool need_coset, bool need_coset_inv, Domain** out) {
-    Domain& d = g.domains[fidx][log_n];
+// Tables are built into locals and committed to the Domain only after every allocation and launch has
+// succeeded: a failed build (e.g. out of memory next to a 100 GB shift table) leaves no half-initialised
+// entry behind for the next call to trip over.
+template <class P> int build_table_checked(Fp** slot, int log_n, const Fp& first, const Fp& base) {
     const size_t N = (size_t)1 << log_n;
-    if (!d.tw) {
+    Fp* t = nullptr;
+    HIPCHK(hipMalloc((void**)&t, N * sizeof(Fp)));
+    int rc = build_pow_table<P>(t, log_n, first, base);
+    if (!rc && hipStreamSynchronize(g.stream) != hipSuccess) { g_err = "building a domain table failed"; rc = GH_E_HIP; }
+    if (rc) { hipFree(t); return rc; }
+    *slot = t;
+    return GH_OK;
+}
+
+template <class P> int get_domain(int fidx, int log_n, bool need_coset, bool need_coset_inv, Domain** out) {
+    auto it = g.domains[fidx].find(log_n);
+    const size_t N = (size_t)1 << log_n;
+    if (it == g.domains[fidx].end()) {
+        Domain d;
         d.log_n = log_n;
         // group_gen = ROOT_OF_UNITY^(2^(s - log_n))   (domain.rs:76-79)
         Fp w = fp_from_abi<P>(reinterpret_cast<const uint32_t*>(FieldConsts<P>::root_m()));
         for (int i = log_n; i < FieldConsts<P>::two_adicity; i++) w = fp_sqr<P>(w);
-        HIPCHK(hipMalloc((void**)&d.tw, N * sizeof(Fp)));
-        int rc = build_pow_table<P>(d.tw, log_n, fp_one<P>(), w);
-        if (rc) return rc;
         // size_inv = (N as field element)^-1, internal form
         Fp n_int = fp_one<P>();
         for (int i = 0; i < log_n; i++) n_int = fp_dbl<P>(n_int);
         d.size_inv = host_fp_inv<P>(n_int);
-        HIPCHK(hipMalloc((void**)&d.scratch, N * 96));
+        hipError_t e = hipMalloc((void**)&d.scratch, N * 96);
+        if (e != hipSuccess) { g_err = std::string("domain scratch: ") + hipGetErrorString(e); return e == hipErrorOutOfMemory ? GH_E_NOMEM : GH_E_HIP; }
+        int rc = build_table_checked<P>(&d.tw, log_n, fp_one<P>(), w);
+        if (rc) { hipFree(d.scratch); return rc; }
+        it = g.domains[fidx].emplace(log_n, d).first;
     }
+    Domain& d = it->second;
     if (need_coset && !d.coset) {
         Fp gen = fp_from_abi<P>(reinterpret_cast<const uint32_t*>(FieldConsts<P>::gen_m()));
-        HIPCHK(hipMalloc((void**)&d.coset, N * sizeof(Fp)));
-        int rc = build_pow_table<P>(d.coset, log_n, fp_one<P>(), gen);
+        int rc = build_table_checked<P>(&d.coset, log_n, fp_one<P>(), gen);
         if (rc) return rc;
     }
     if (need_coset_inv && !d.coset_inv) {
         Fp gen = fp_from_abi<P>(reinterpret_cast<const uint32_t*>(FieldConsts<P>::gen_m()));
         Fp gi = host_fp_inv<P>(gen);
-        HIPCHK(hipMalloc((void**)&d.coset_inv, N * sizeof(Fp)));
-        int rc = build_pow_table<P>(d.coset_inv, log_n, d.size_inv, gi);
+        int rc = build_table_checked<P>(&d.coset_inv, log_n, d.size_inv, gi);
         if (rc) return rc;
     }
     *out = &d;

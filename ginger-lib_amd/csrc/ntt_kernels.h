@@ -216,9 +216,12 @@ __global__ void __launch_bounds__(256) witness_finish_kernel(const uint32_t* ab,
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i > N) return;
     Fp v;
+    // (N == 1: h[..N-1] is empty in the reference, so h[0] = -d3 - d1 d2 -- the i == 0 term applies to the zero)
     if (i == N) v = h_last;
-    else if (i == N - 1) v = fp_zero();
-    else { v = ld_abi_raw(ab + i * 24); if (i == 0) v = fp_add<P>(v, h0_add); }
+    else {
+        v = i == N - 1 ? fp_zero() : ld_abi_raw(ab + i * 24);
+        if (i == 0) v = fp_add<P>(v, h0_add);
+    }
     st_abi_raw(h + i * 24, v);
 }
 

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <string>
@@ -39,10 +40,11 @@ struct Ctx {
     std::map<int, Domain> domains[2];
     std::map<std::string, DevBuf> pool;
     int window_override = 0;
-    int affine_mode = 0;        // 1: G1 bucket sums on a shift table in affine coordinates (msm_kernels.h 4c)
+    int affine_mode = 2;        // G1 bucket sums by affine rounds (aff_kernels.h): 0 never, 1 always, 2 when the list fills the chip
     gh_msm_timing_t last_msm{};
     std::vector<gh_msm_timing_t> batch_tm;   // per-MSM timings of the last batch call
     float last_fft_ms = 0;
+    std::vector<std::function<void()>> at_shutdown;   // releases of function-local device / pinned allocations
 };
 
 extern Ctx g;
@@ -50,7 +52,7 @@ extern std::string g_err;
 
 int ensure_init();
 int pool_get(const char* name, size_t bytes, void** out);
-int device_scan(const uint32_t* in, uint32_t* out, size_t n, const char* tmpname);
+int device_scan(const uint32_t* in, uint32_t* out, size_t n, const char* tmpname, hipStream_t stream = nullptr);   // nullptr: g.stream
 int auto_window(size_t n, int deg);
 
 #define HIPCHK(call)                                                                         \

@@ -38,6 +38,67 @@ def all_gather_fold(partial_xyz, proj_add, dist=None, device=None):
     return acc
 
 
+class CDist:
+    """The exchange behind the C ABI (include/ginger_hip_dist.h): gh_dist_init_rccl / gh_dist_init_custom +
+    gh_partials_allgather_fold.  transport = "rccl": RCCL over xGMI -- the 128-byte unique id travels from rank 0
+    through `store` (a torch.distributed store, e.g. the TCPStore torchrun's MASTER_ADDR / MASTER_PORT give);
+    transport = "callback": any all-gather as a Python callable (gloo in the CPU tests)."""
+
+    def __init__(self, gl, rank, world, transport="rccl", store=None, allgather=None):
+        import ctypes
+        self.gl, self.rank, self.world = gl, rank, world
+        lib = gl.load_library()
+        if transport == "rccl":
+            uid = (ctypes.c_char * 128)()
+            if rank == 0:
+                gl._check(lib.gh_dist_unique_id(uid))
+                store.set("gh_dist_uid", bytes(uid.raw))
+            else:
+                uid.raw = store.get("gh_dist_uid")
+            gl._check(lib.gh_dist_init_rccl(uid, rank, world))
+        else:
+            def _cb(_ctx, send, recv, nbytes):
+                try:
+                    data = ctypes.string_at(send, nbytes)
+                    out = allgather(data)
+                    assert len(out) == nbytes * world
+                    ctypes.memmove(recv, out, len(out))
+                    return 0
+                except Exception:       # noqa: a Python error must not unwind through the C frame
+                    return 1
+            self._cb = gl.ALLGATHER_FN(_cb)       # keep the thunk alive
+            gl._check(lib.gh_dist_init_custom(self._cb, None, rank, world))
+        r, w = ctypes.c_int(), ctypes.c_int()
+        gl._check(lib.gh_dist_info(ctypes.byref(r), ctypes.byref(w)))
+        self.world_seen = w.value              # ranks the transport itself reports (ncclCommCount)
+        self.last_exchange_us = 0.0
+
+    def allgather_fold(self, curve, partial_xyz):
+        import ctypes
+        gl = self.gl
+        p = np.ascontiguousarray(partial_xyz, dtype=np.uint64)
+        out = np.zeros_like(p)
+        us = ctypes.c_double()
+        gl._check(gl.load_library().gh_partials_allgather_fold(gl.CURVES[curve], gl._ptr(p), gl._ptr(out), ctypes.byref(us)))
+        self.last_exchange_us = us.value
+        return out
+
+    def shutdown(self):
+        self.gl.load_library().gh_dist_shutdown()
+
+
+def gloo_allgather_bytes(dist):
+    """all-gather of a byte string over a torch.distributed (gloo) group, for CDist(transport="callback")"""
+    import torch
+
+    def fn(data):
+        t = torch.frombuffer(bytearray(data), dtype=torch.uint8)
+        parts = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+        dist.all_gather(parts, t)
+        return b"".join(bytes(p.numpy().tobytes()) for p in parts)
+    return fn
+
+
 class ShardedMSM:
     """Holds this rank's shard of the bases resident on its GPU; multi_scalar_mul() takes this
     rank's shard of the scalars and returns the global sum on every rank.

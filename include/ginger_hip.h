@@ -127,13 +127,12 @@ int gh_msm_resident_dev_batch(const gh_bases_t* handles, const void* const* d_sc
 /* Window size override for sweeps (0 = automatic).  Affects subsequent MSM calls. */
 int gh_msm_set_window(int c);
 int gh_msm_get_window(gh_curve_t curve, size_t n);
-/* Experimental (default off): on a G1 key with a shift table, sum the buckets in AFFINE coordinates --
- * pairwise rounds, one safegcd inversion per lane and round via Montgomery's trick (~6 field products
- * per addition instead of 11); additions with equal x and over-long buckets fall back to the projective
- * kernel.  Same results; currently slower than the projective kernel.
- * on: 0 off, 1 pairwise rounds all in affine, 2 one affine round + mixed additions over lane slices,
- * 3 the same with one bucket per lane.                                                              */
-int gh_msm_set_affine(int on);
+/* Bucket sums in AFFINE coordinates (G1): pairwise rounds over the flat bucket-ordered list, the inversions
+ * of a lane's whole batch shared by Montgomery's trick (5 M + 1 S + a share of one safegcd inversion per
+ * addition instead of the 11 M of add_assign_mixed); P + P, P - P and sums through infinity handled in place.
+ * Same results as the projective kernel.  mode: 0 never, 1 always, 2 (default) when the list is long enough
+ * to fill the chip -- short MSMs stay projective, a round costs at least one inversion's latency.        */
+int gh_msm_set_affine(int mode);
 
 /* Time spent by the last MSM call in its phases, milliseconds (device phases by HIP events on the
  * library stream, host fold by a host clock).  Any pointer may be NULL. */
@@ -203,6 +202,10 @@ int gh_dev_free(void* d_ptr);
 int gh_dev_upload(void* d_dst, const void* h_src, size_t bytes);
 int gh_dev_download(void* h_dst, const void* d_src, size_t bytes);
 int gh_dev_sync(void);
+/* Release the library's cached scratch buffers (bucket lists, affine-round lists, staging); they are
+ * re-allocated on demand.  For a host that is done with a large key and wants the HBM back; resident
+ * bases, shift tables and domain tables are not touched.                                          */
+int gh_dev_trim(void);
 
 /* ---- group helpers on the host side of the boundary -------------------------------------- */
 /* acc = acc + p for two projective points in the MSM result format (used to fold the per-GPU

@@ -10,8 +10,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def header_functions():
-    src = open(os.path.join(ROOT, "include", "ginger_hip.h")).read()
+def header_functions(name="ginger_hip.h"):
+    src = open(os.path.join(ROOT, "include", name)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(gh_\w+)\s*\(", src)))
 
@@ -23,6 +23,10 @@ def test_every_declared_symbol_is_exported(gl):
     for n in names:
         assert hasattr(lib, n), n
     assert sorted(gl.ABI_SYMBOLS) == names
+    dist = header_functions("ginger_hip_dist.h")
+    assert len(dist) == 6 and sorted(gl.DIST_SYMBOLS) == dist
+    for n in dist:
+        assert hasattr(lib, n), n
 
 
 def test_library_has_no_oracle_dependency():

@@ -34,9 +34,16 @@ def _worker(rank, world, port, curve, n, ret):
                                  lambda acc, p: gl.proj_add(curve, acc, p))
     total = sharded.multi_scalar_mul(s[lo:hi])
     xy, is_inf = gl.proj_to_affine(curve, total)
+    # the same exchange through the C entry point (include/ginger_hip_dist.h) with gloo as the transport
+    cd = distmod.CDist(gl, rank, world, transport="callback", allgather=distmod.gloo_allgather_bytes(dist))
+    partial = S.oracle_msm(curve, b[lo:hi], inf[lo:hi], s[lo:hi], 2)
+    total_c = cd.allgather_fold(curve, partial)
+    xy_c, inf_c = gl.proj_to_affine(curve, total_c)
+    c_ok = cd.world_seen == world and inf_c == is_inf and bool((xy_c == xy).all())
+    cd.shutdown()
     full = S.oracle_msm(curve, b, inf, s, 2)
     exy, einf = S.oracle_affine(curve, full)
-    ok = (is_inf == einf) and bool((xy == exy).all())
+    ok = c_ok and (is_inf == einf) and bool((xy == exy).all())
     ret[rank] = ok
     dist.destroy_process_group()
 

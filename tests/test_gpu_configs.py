@@ -1,0 +1,281 @@
+"""GPU parity at every BASELINE.json config size (the sizes test_gpu_parity.py does not reach):
+  config 3  MNT4-753 G1 at 2^24 pairs (shift table c = 23 and per-window path),
+  config 4  MNT6-753 G1 and G2 at the 8-GPU shard size 2^19 and at 2^22 on one GPU; MNT4-753 G2 at 2^20,
+  config 5  the device halves of create_proof at 2^20 constraints (witness map + MSM stage),
+plus the G2 lane-pair / lane-triple kernels on inputs with heavy buckets, L1 = 16 segments, several
+pseudo-windows and pipelined batches, and the C ABI called from two threads.
+Full-size results are checked through size-independent properties (table path == per-window path == other
+window sizes in affine, linearity on a slice) and an oracle spot check on a slice of the same inputs
+(reference semantics: algebra/src/msm/variable_base.rs:10-90, proof-systems/src/groth16/prover.rs:273-345)."""
+import importlib
+import threading
+
+import numpy as np
+import pytest
+
+import pyref
+import support as S
+
+pytestmark = pytest.mark.gpu
+
+
+def affine(gl, curve, xyz):
+    xy, inf = gl.proj_to_affine(curve, xyz)
+    return inf, xy.tobytes()
+
+
+def oracle_affine(curve, xyz):
+    xy, inf = S.oracle_affine(curve, xyz)
+    return inf, xy.tobytes()
+
+
+def tiled_bases(curve, n, pool_n, seed):
+    C = pyref.CURVES[curve]
+    pool = S.chain_points(C, pool_n, pyref.Rng(seed))
+    pb, _ = S.bases_array(C, pool)
+    return np.tile(pb, (n // pool_n, 1)), pool
+
+
+def add_mod(a, b, r):
+    out = np.empty_like(a)
+    for i in range(len(a)):
+        out[i] = pyref.int_to_limbs((pyref.limbs_to_int([int(v) for v in a[i]]) + pyref.limbs_to_int([int(v) for v in b[i]])) % r)
+    return out
+
+
+def skew(s, r):
+    """witness-like scalars: a third 1, some 0 / 2 / r - 1 / one repeated value: long buckets, the scalar == 1 shortcut"""
+    s = s.copy()
+    s[0::3, :] = 0
+    s[0::3, 0] = 1
+    s[1::15, :] = 0
+    s[4::15, :] = 0
+    s[4::15, 0] = 2
+    s[7::15] = np.array(pyref.int_to_limbs(r - 1), dtype=np.uint64)
+    s[10::15] = s[10]
+    return s
+
+
+# ------------------------------------------------------------------------------ config 3 at 2^24
+def test_cfg3_mnt4_g1_2p24(gpu):
+    curve = "mnt4753_g1"
+    C = pyref.CURVES[curve]
+    r = C.order
+    n = 1 << 24
+    bases, _ = tiled_bases(curve, n, 4096, 2024)
+    s = S.random_scalars_np(n, seed=31, below=r)
+    rb = gpu.ResidentBases(curve, bases)
+    ds = gpu.DeviceBuffer(s.nbytes).upload(s)
+    try:
+        plain = affine(gpu, curve, rb.msm_dev(ds, n))                   # per-window path, c from n
+        tm = gpu.msm_last_timing()
+        assert tm["num_windows"] == 752 // tm["window_bits"] + 1 and tm["accumulate_madds"] > 0.85 * n * tm["num_windows"]
+        # linearity on a 2^17 slice and the oracle on a 2^14 slice of the same inputs
+        m, k = 1 << 17, 1 << 14
+        t = S.random_scalars_np(m, seed=32, below=r)
+        st = add_mod(s[:m], t, r)
+        lhs = gpu.proj_add(curve, rb.msm(s[:m]), rb.msm(t))
+        assert affine(gpu, curve, lhs) == affine(gpu, curve, rb.msm(st))
+        exp = S.oracle_msm(curve, bases[:k], None, s[:k], 16)
+        assert affine(gpu, curve, rb.msm(s[:k])) == oracle_affine(curve, exp)
+        # shift table: c = 23, 33 rows, 115 GB
+        assert rb.precompute(0) == 23
+        table = affine(gpu, curve, rb.msm_dev(ds, n))
+        assert gpu.msm_last_timing()["num_windows"] == 33
+        assert table == plain
+        assert affine(gpu, curve, rb.msm(s[:k])) == oracle_affine(curve, exp)
+        # projective bucket sums give the same point as the affine rounds (whichever the automatic mode picked)
+        gpu.msm_set_affine(0)
+        assert affine(gpu, curve, rb.msm_dev(ds, n)) == plain
+    finally:
+        gpu.msm_set_affine(2)
+        ds.free()
+        rb.free()
+        gpu.dev_trim()
+
+
+# ------------------------------------------------------------------------------ config 4 shapes
+@pytest.mark.parametrize("curve,log_n,pool_n,with_table", [("mnt6753_g1", 19, 4096, True), ("mnt6753_g1", 22, 4096, True),
+                                                          ("mnt6753_g2", 19, 512, True), ("mnt6753_g2", 22, 512, False),
+                                                          ("mnt4753_g2", 20, 512, True)])
+def test_cfg4_shapes(gpu, curve, log_n, pool_n, with_table):
+    C = pyref.CURVES[curve]
+    r = C.order
+    n = 1 << log_n
+    bases, _ = tiled_bases(curve, n, pool_n, 77 + log_n)
+    s = S.random_scalars_np(n, seed=41 + log_n, below=r)
+    rb = gpu.ResidentBases(curve, bases)
+    ds = gpu.DeviceBuffer(s.nbytes).upload(s)
+    try:
+        ref = affine(gpu, curve, rb.msm_dev(ds, n))
+        c0 = gpu.msm_last_timing()["window_bits"]
+        gpu.msm_set_window(c0 - 2)                                      # window-size invariance
+        assert affine(gpu, curve, rb.msm_dev(ds, n)) == ref
+        assert gpu.msm_last_timing()["window_bits"] == c0 - 2
+        gpu.msm_set_window(0)
+        k = 1 << (13 if C.deg == 1 else 12)                             # oracle spot check on a slice
+        exp = S.oracle_msm(curve, bases[:k], None, s[:k], 16)
+        assert affine(gpu, curve, rb.msm(s[:k])) == oracle_affine(curve, exp)
+        if with_table:
+            c = rb.precompute(0)
+            assert affine(gpu, curve, rb.msm_dev(ds, n)) == ref
+            assert gpu.msm_last_timing()["window_bits"] == c
+            assert affine(gpu, curve, rb.msm(s[:k])) == oracle_affine(curve, exp)
+    finally:
+        gpu.msm_set_window(0)
+        ds.free()
+        rb.free()
+        gpu.dev_trim()
+
+
+@pytest.mark.parametrize("curve,log_n", [("mnt4753_g2", 15), ("mnt6753_g2", 14), ("mnt6753_g1", 16)])
+def test_split_kernels_heavy_buckets_batch_vs_oracle(gpu, curve, log_n):
+    """mid-size oracle parity with skewed scalars (heavy buckets and chunks), duplicate and opposite bases, with and
+    without the shift table (several pseudo-windows, L1 = 16 segments), and as a pipelined batch of 4 MSMs"""
+    C = pyref.CURVES[curve]
+    r = C.order
+    n = 1 << log_n
+    bases, pool = tiled_bases(curve, n, 256, 5 + log_n)
+    # duplicate and opposite bases next to each other, with equal scalars: P + P and P - P inside one bucket
+    negp = S.bases_array(C, [C.neg(p) for p in pool[:64]])[0]
+    bases[64:128] = negp
+    s = skew(S.random_scalars_np(n, seed=51 + log_n, below=r), r)
+    s[64:128] = s[0:64]
+    s[256:320] = s[0:64]
+    t = S.random_scalars_np(n, seed=52 + log_n, below=r)
+    exp_s = oracle_affine(curve, S.oracle_msm(curve, bases, None, s, 16))
+    exp_t = oracle_affine(curve, S.oracle_msm(curve, bases, None, t, 16))
+    half = n // 2 + 3
+    exp_h = oracle_affine(curve, S.oracle_msm(curve, bases, None, s[:half], 16))
+    rb = gpu.ResidentBases(curve, bases)
+    ds, dt = gpu.DeviceBuffer(s.nbytes).upload(s), gpu.DeviceBuffer(t.nbytes).upload(t)
+    try:
+        for table in (False, True):
+            if table:
+                rb.precompute(0)
+            assert affine(gpu, curve, rb.msm_dev(ds, n)) == exp_s, (curve, table)
+            if not table:
+                assert gpu.msm_last_timing()["heavy_buckets"] > 0 or C.deg == 1
+            outs = gpu.msm_batch_dev([(rb, ds, n), (rb, dt, n), (rb, ds, half), (rb, dt, n)])
+            got = [affine(gpu, curve, o) for o in outs]
+            assert got == [exp_s, exp_t, exp_h, exp_t], (curve, table)
+        if C.deg == 1:            # both forms of the bucket sums on the same skewed input
+            for mode in (0, 1):
+                gpu.msm_set_affine(mode)
+                assert affine(gpu, curve, rb.msm_dev(ds, n)) == exp_s, (curve, "affine mode", mode)
+    finally:
+        gpu.msm_set_affine(2)
+        ds.free(); dt.free()
+        rb.free()
+        gpu.dev_trim()
+
+
+# ------------------------------------------------------------------------------ config 5 at 2^20
+def _replay(gpu, log_n, with_oracle):
+    """device halves of create_proof for a 2^log_n-constraint MNT4-753 circuit (tools/prover_replay.py as a test)"""
+    groth16 = importlib.import_module("ginger_lib_amd.groth16")
+    from test_groth16_stage import _oracle_stage
+    pairing = "mnt4753"
+    C1, C2 = pyref.CURVES[pairing + "_g1"], pyref.CURVES[pairing + "_g2"]
+    N = 1 << log_n
+    ni, nv = 3, N - 1
+    rng = pyref.Rng(5)
+    b1 = S.bases_array(C1, S.chain_points(C1, 1 << 10, rng))[0]
+    b2 = S.bases_array(C2, S.chain_points(C2, 1 << 6, rng))[0]
+    tile1 = lambda m, shift: np.roll(np.tile(b1, (m // len(b1) + 1, 1)), shift, axis=0)[:m]
+    pk = {"a_query": tile1(nv, 0), "b_g1_query": tile1(nv, 3), "h_query": tile1(N - 1, 7), "l_query": tile1(nv - ni, 11),
+          "b_g2_query": np.tile(b2, (nv // len(b2) + 1, 1))[:nv],
+          "alpha_g1": b1[5], "beta_g1": b1[6], "delta_g1": b1[7], "beta_g2": b2[5], "delta_g2": b2[7]}
+    r_ord = C1.order
+    F = "mnt4753_fr"
+    a, b, c = (S.random_scalars_np(N, seed=s0, below=r_ord) for s0 in (1, 2, 3))
+    d = S.random_scalars_np(3, seed=4, below=r_ord)
+    assign = S.random_scalars_np(nv - 1, seed=9, below=r_ord)
+    assign[::7] = 0
+    assign[1::7, 1:] = 0
+    assign[1::7, 0] = 1
+    r, s = S.random_scalars_np(2, seed=10, below=r_ord)
+    lib = gpu.load_library()
+    one_plain = np.zeros(12, dtype=np.uint64)
+    one_plain[0] = 1
+    results = []
+    h = None
+    for precompute in (True, False):
+        key = groth16.ResidentProvingKey(gpu, pairing, pk, ni, precompute=precompute)
+        da, db, dc, dh = (gpu.DeviceBuffer(N * 96 + 96) for _ in range(4))
+        try:
+            da.upload(a); db.upload(b); dc.upload(c)
+            gpu._check(lib.gh_witness_map_dev(gpu.FIELDS[F], da.ptr, db.ptr, dc.ptr, log_n, gpu._ptr(d[0]), gpu._ptr(d[1]), gpu._ptr(d[2]), dh.ptr))
+            gpu._check(lib.gh_vec_scale_dev(gpu.FIELDS[F], dh.ptr, gpu._ptr(one_plain), N + 1))       # into_repr (prover.rs:256-267)
+            proof = key.create_proof_msms(assign[:ni - 1], assign[ni - 1:], None, None, r, s, h_dev=(dh, N - 1))
+            results.append([(inf, np.asarray(xy).tobytes()) for xy, inf in proof])
+            if h is None:
+                h = dh.download()[:(N - 1) * 12].reshape(N - 1, 12).copy()
+        finally:
+            for x in (da, db, dc, dh):
+                x.free()
+            key.free()
+    assert results[0] == results[1]                    # table path == per-window path, A, B and C
+    if with_oracle:
+        hm = S.oracle_witness_map(F, a, b, c, d[0], d[1], d[2])
+        # the oracle's h is in Montgomery form; into_repr on the oracle side: multiply by the plain integer 1
+        exp = _oracle_stage(pairing, pk, ni, assign[:ni - 1], assign[ni - 1:], h[:ni], h[ni:], r, s)
+        assert results[0] == [(inf, np.asarray(xy).tobytes()) for xy, inf in exp]
+        hm_plain = np.array([pyref.int_to_limbs(v) for v in S.fe_list(S.FIELD_OF[F], hm[:N - 1])], dtype=np.uint64)
+        assert (hm_plain == h).all()
+    gpu.dev_trim()
+
+
+def test_cfg5_replay_2p16_vs_oracle(gpu):
+    """witness map + into_repr + MSM stage at 2^16 constraints against the oracle's literal replay (nine MSMs)"""
+    _replay(gpu, 16, True)
+
+
+def test_cfg5_replay_2p20(gpu):
+    """the same at BASELINE config 5's size: A, B, C from the table path and from the per-window path agree"""
+    _replay(gpu, 20, False)
+
+
+# ------------------------------------------------------------------------------ the C ABI from two threads
+def test_abi_two_threads(gpu):
+    """include/ginger_hip.h: "calls are serialised by an internal lock and may come from any thread" -- two threads
+    issue host-buffer MSMs and transforms with different inputs and sizes at the same time; each must get its own result"""
+    curve = "mnt4753_g1"
+    C = pyref.CURVES[curve]
+    rng = pyref.Rng(8)
+    pts = S.chain_points(C, 700, rng)
+    b, inf = S.bases_array(C, pts)
+    rb = gpu.ResidentBases(curve, b, inf)
+    jobs = []
+    for i, n in enumerate((700, 300, 650, 120)):
+        s = S.scalar_array([rng.field_elem(C.order) for _ in range(n)])
+        jobs.append((s, oracle_affine(curve, S.oracle_msm(curve, b, inf, s, 8))))
+    ffts = []
+    for i, lg in enumerate((10, 12, 9, 11)):
+        a = S.random_scalars_np(1 << lg, seed=60 + i, below=pyref.P6.p)
+        ffts.append((a, lg, S.oracle_fft("mnt4753_fr", a, lg, i & 3)))
+    errors = []
+
+    def worker(tid):
+        try:
+            for rep in range(6):
+                j = (tid * 2 + rep) % 4
+                s, exp = jobs[j]
+                got = rb.msm(s) if rep % 2 else gpu.VariableBaseMSM.multi_scalar_mul(curve, b, s, inf)
+                if affine(gpu, curve, got) != exp:
+                    errors.append(("msm", tid, rep))
+                a, lg, ref = ffts[j]
+                dom = gpu.EvaluationDomain("mnt4753_fr", 1 << lg)
+                out = dom._run(a, j & 3).reshape(-1, 12)
+                if not (out == ref).all():
+                    errors.append(("fft", tid, rep))
+        except Exception as e:     # noqa
+            errors.append(("exception", tid, repr(e)))
+
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    rb.free()
+    assert not errors, errors

@@ -99,7 +99,7 @@ def test_vec_ops(gpu):
     assert (got == exp).all()
 
 
-@pytest.mark.parametrize("field,log_n", [("mnt4753_fr", 1), ("mnt4753_fr", 10), ("mnt4753_fr", 15), ("mnt6753_fr", 9)])
+@pytest.mark.parametrize("field,log_n", [("mnt4753_fr", 0), ("mnt4753_fr", 1), ("mnt4753_fr", 10), ("mnt4753_fr", 15), ("mnt6753_fr", 9)])
 def test_witness_map_vs_oracle(gpu, field, log_n):
     """R1CStoQAP::witness_map transform pipeline (r1cs_to_qap.rs:121-166), arbitrary rows and d1 d2 d3"""
     F = S.FIELD_OF[field]
@@ -411,10 +411,11 @@ def test_msm_batch_pipelined(gpu):
 
 @pytest.mark.parametrize("curve,n,windows", [("mnt4753_g1", 3000, (0, 9, 13)), ("mnt6753_g1", 700, (0, 12))])
 def test_msm_affine_bucket_sums_vs_oracle(gpu, curve, n, windows):
-    """gh_msm_set_affine(1): bucket sums in affine coordinates (pairwise rounds, batched safegcd inversion).
-    Duplicate and opposite bases in one bucket (equal x -> flagged -> projective fallback), buckets of every
-    length incl. longer than the private buffers (c = 9: hundreds of entries per bucket -> fallback / chunks),
-    zero / one / r - 1 scalars, an infinity base; same affine result as the oracle and as the projective path."""
+    """gh_msm_set_affine(1): bucket sums by affine rounds (aff_kernels.h: pairwise rounds over the flat list, batched
+    safegcd inversion).  Duplicate and opposite bases in one bucket (doubling / cancellation handled in the round),
+    sums that pass through infinity, buckets of every length (c = 9: hundreds of entries per bucket; many equal small
+    scalars: thousands -> extra rounds), zero / one / r - 1 scalars, an infinity base; on a shift table and on the
+    per-window path; same affine result as the oracle and as the projective kernel."""
     C = pyref.CURVES[curve]
     r = C.order
     rng = pyref.Rng(777 + n)
@@ -431,21 +432,53 @@ def test_msm_affine_bucket_sums_vs_oracle(gpu, curve, n, windows):
     b, inf = S.bases_array(C, pts)
     s = S.scalar_array(scal)
     exp = S.oracle_msm(curve, b, inf, s, 16)
+    exp_short = S.oracle_msm(curve, b, inf, s[:n // 2], 16)
     rb = gpu.ResidentBases(curve, b, inf)
     try:
+        for mode in (1, 0):
+            gpu.msm_set_affine(mode)
+            for c in (0, 5, 13):          # per-window path (no table yet), automatic and forced window sizes
+                gpu.msm_set_window(c)
+                assert affine_eq(gpu, curve, rb.msm(s), exp), (curve, "per-window", c, mode)
+                assert affine_eq(gpu, curve, gpu.VariableBaseMSM.multi_scalar_mul(curve, b, s[:n // 2], inf), exp_short), (curve, c, mode)
+            gpu.msm_set_window(0)
         for c in windows:
             rb.precompute(c)
-            exp_short = S.oracle_msm(curve, b, inf, s[:n // 2], 16)
-            for mode in (1, 2, 3):            # 1: pairwise rounds (4c); 2: one affine round + mixed additions, lane slices (4d); 3: the same, one bucket per lane (4e)
+            for mode in (1, 0):
                 gpu.msm_set_affine(mode)
-                got = rb.msm(s)
-                assert affine_eq(gpu, curve, got, exp), (curve, c, "affine mode", mode)
+                assert affine_eq(gpu, curve, rb.msm(s), exp), (curve, c, "affine mode", mode)
                 assert affine_eq(gpu, curve, rb.msm(s[:n // 2]), exp_short), (curve, c, "short", mode)
-            gpu.msm_set_affine(0)
-            assert affine_eq(gpu, curve, rb.msm(s), exp), (curve, c, "projective")
     finally:
-        gpu.msm_set_affine(0)
+        gpu.msm_set_affine(2)
+        gpu.msm_set_window(0)
         rb.free()
+
+
+@pytest.mark.parametrize("curve", ["mnt4753_g1", "mnt6753_g1"])
+def test_msm_affine_degenerate_inputs(gpu, curve):
+    """affine rounds on inputs made of the group law's special cases only: all bases equal (every addition of every
+    round is a doubling), bases in opposite pairs with equal scalars (every bucket cancels to infinity), a single pair,
+    all scalars zero"""
+    C = pyref.CURVES[curve]
+    r = C.order
+    rng = pyref.Rng(91)
+    P, Q = S.chain_points(C, 2, rng)
+    k = rng.field_elem(r)
+    cases = [([P] * 257, [k] * 257), ([P, C.neg(P)] * 100, [k] * 200), ([P, C.neg(P)] * 64 + [Q], [k] * 128 + [5]),
+             ([P], [k]), ([P, Q, P], [0, 0, 0]), ([P] * 70 + [C.neg(P)] * 70, list(range(1, 71)) * 2)]
+    gpu.msm_set_affine(1)
+    try:
+        for pts, scal in cases:
+            b, inf = S.bases_array(C, pts)
+            s = S.scalar_array(scal)
+            exp = S.oracle_msm(curve, b, inf, s, 8)
+            assert affine_eq(gpu, curve, gpu.VariableBaseMSM.multi_scalar_mul(curve, b, s, inf), exp), len(pts)
+            rb = gpu.ResidentBases(curve, b, inf)
+            rb.precompute(7)
+            assert affine_eq(gpu, curve, rb.msm(s), exp), (len(pts), "table")
+            rb.free()
+    finally:
+        gpu.msm_set_affine(2)
 
 
 # ------------------------------------------------------------------------------ proving-key wire format
