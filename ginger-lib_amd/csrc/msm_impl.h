@@ -533,11 +533,13 @@ struct MsmJob {
         static const int env_R = getenv("GH_AFF_ROUNDS") ? atoi(getenv("GH_AFF_ROUNDS")) : 0;
         static const int env_bmin = getenv("GH_AFF_BMIN") ? atoi(getenv("GH_AFF_BMIN")) : 8;
         static const int env_fin = getenv("GH_AFF_FINISH_MAX") ? atoi(getenv("GH_AFF_FINISH_MAX")) : 64;
-        // rounds: down to ~2 points per bucket on average, and no bucket left with more than env_fin points
+        // rounds: down to ~env_left points per bucket on average (the late rounds are short batches -- one inversion per
+        // lane and round -- while the projective finish is dense work), and no bucket left with more than env_fin points
+        static const double env_left = getenv("GH_AFF_LEFTOVER") ? atof(getenv("GH_AFF_LEFTOVER")) : 4.5;
         int R = 1;
         {
             const double mean = (double)n0 / (double)(total > 1 ? total - 1 : 1);
-            while (R < AFF_MAX_ROUNDS && (double)(1u << (R + 1)) < mean) R++;
+            while (R < AFF_MAX_ROUNDS && (double)(1u << R) * env_left < mean) R++;
             if (env_R > 0) R = env_R;
             while (R < AFF_MAX_ROUNDS && (maxc >> R) > (uint32_t)env_fin) R++;
         }
@@ -565,8 +567,8 @@ struct MsmJob {
         size_t n_desc = 0;
         for (int r = 1; r <= R; r++) n_desc += hn[r];
         uint32_t* desc;
-        Aff<C>*ptsA, *ptsB;
-        Fp* prefix;
+        void *ptsA, *ptsB, *prefix, *stage1, *stage2;     // T64 lists (aff_kernels.h)
+        auto tiles = [&](uint32_t n_el) { return ((size_t)n_el + TPW - 1) / TPW + 1; };
 #undef POOLT
 #define POOLBIG(name, ptr, bytes)                                   \
     snprintf(nm, sizeof nm, "%s#%d", name, slot);                   \
@@ -574,16 +576,19 @@ struct MsmJob {
     if (rc == GH_E_NOMEM) { (void)hipGetLastError(); tree = false; return GH_OK; } \
     if (rc) return rc;
         POOLBIG("aff_desc", desc, (n_desc + 64) * 4)
-        POOLBIG("aff_ptsA", ptsA, ((size_t)hn[1] + 64) * sizeof(Aff<C>))
-        POOLBIG("aff_ptsB", ptsB, ((size_t)(R >= 2 ? hn[2] : 0) + 64) * sizeof(Aff<C>))
-        POOLBIG("aff_prefix", prefix, ((size_t)hn[1] + 64) * LANES * sizeof(Fp))
+        POOLBIG("aff_ptsA", ptsA, t64_bytes(tiles(hn[1]), T64_PT_CHUNKS))
+        POOLBIG("aff_ptsB", ptsB, t64_bytes(tiles(R >= 2 ? hn[2] : 0), T64_PT_CHUNKS))
+        POOLBIG("aff_prefix", prefix, t64_bytes(tiles(hn[1]), T64_FP_CHUNKS))
+        POOLBIG("aff_stage1", stage1, t64_bytes(tiles(hn[1]), T64_PT_CHUNKS))
+        POOLBIG("aff_stage2", stage2, t64_bytes(tiles(hn[1]), T64_PT_CHUNKS))
 #undef POOLBIG
         const uint32_t max_waves = (uint32_t)g.num_cus * 4u * (uint32_t)FS::WAVES;
         size_t doff = 0;
-        const Aff<C>* in = (const Aff<C>*)(merged ? h->d_table : h->d_points);
+        const Aff<C>* rows = (const Aff<C>*)(merged ? h->d_table : h->d_points);
+        const void* in = nullptr;
         for (int r = 0; r < R; r++) {
             const uint32_t n_out = hn[r + 1];
-            Aff<C>* out = (r & 1) ? ptsB : ptsA;
+            void* out = (r & 1) ? ptsB : ptsA;
             if (n_out > 0) {
                 const uint32_t* st_in = r == 0 ? starts : aff_st + (size_t)(r - 1) * stride;
                 const uint32_t* m_in = r == 0 ? counts : aff_cnt + (size_t)(r - 1) * stride;
@@ -596,15 +601,16 @@ struct MsmJob {
                 if (waves > max_waves) waves = max_waves;
                 waves = (waves + 3u) & ~3u;
                 AffRoundArgs<C> a;
-                a.in = in; a.sorted = r == 0 ? sorted : nullptr; a.desc = desc + doff; a.n_out_p = aff_nout + r + 1;
-                a.prefix = prefix; a.out = out; a.groups = waves * TPW; a.bmin = (uint32_t)env_bmin;
-                hipLaunchKernelGGL((aff_round_kernel<C, FS>), dim3(waves / 4), dim3(256), 0, st, a);
+                a.rows = rows; a.in = in; a.sorted = r == 0 ? sorted : nullptr; a.desc = desc + doff; a.n_out_p = aff_nout + r + 1;
+                a.prefix = prefix; a.out = out; a.stage1 = stage1; a.stage2 = stage2; a.groups = waves * TPW; a.bmin = (uint32_t)env_bmin;
+                if (r == 0) hipLaunchKernelGGL((aff_round_kernel<C, FS, true>), dim3(waves / 4), dim3(256), 0, st, a);
+                else hipLaunchKernelGGL((aff_round_kernel<C, FS, false>), dim3(waves / 4), dim3(256), 0, st, a);
             }
             doff += n_out;
             in = out;
         }
         // what is left (about two points per bucket): projective, one bucket per thread, longest first
-        hipLaunchKernelGGL((msm_accumulate_kernel<C, 2, true>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, in,
+        hipLaunchKernelGGL((msm_accumulate_kernel<C, 2, true>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const Aff<C>*)in,
                            (const uint32_t*)nullptr, (const uint32_t*)(aff_st + (size_t)(R - 1) * stride),
                            (const uint32_t*)(aff_cnt + (size_t)(R - 1) * stride), (const uint32_t*)order, (uint32_t)total,
                            (const Aff<C>*)salts, buckets, (const uint32_t*)chunk_start, 0u, 0u, heavy_chunk, (Proj<C>*)nullptr);

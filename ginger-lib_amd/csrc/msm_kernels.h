@@ -447,8 +447,11 @@ msm_accumulate_kernel(const Aff<C>* __restrict__ bases, const uint32_t* __restri
             q = ld_aff<C>(salts + salt_id);
             if (phase == 3) q.y = F::neg(q.y);
         } else {
-            if constexpr (AFFIN) {
-                q = ld_aff<C>(bases + beg + k);
+            if constexpr (AFFIN) {   // T64 list (aff_kernels.h): element e in tile e / 64, slot e % 64
+                static_assert(!AFFIN || F::DEG == 1, "affine-round lists: prime-field curves");
+                const uint32_t e = beg + k;
+                F::comp(q.x, 0) = t64_ld_x(bases, e >> 6, e & 63u);
+                F::comp(q.y, 0) = t64_ld_y(bases, e >> 6, e & 63u);
                 if (phase == 0 && F::comp(q.x, 0).l[0] == AFF_MARK) { k++; continue; }   // a cancelled pair: nothing to add
             } else {
                 const uint32_t e = sorted[beg + k];

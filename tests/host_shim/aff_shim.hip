@@ -30,23 +30,28 @@ static int run_tree(const uint64_t* bases_xy, size_t n_bases, const uint32_t* so
         for (uint32_t b = 0; b < total; b++) { st[(size_t)(r - 1) * stride + b] = run; run += cnt[(size_t)(r - 1) * stride + b]; }
         nout[r] = run;
     }
-    std::vector<Aff<C>> bufA(nout[1] + 1), bufB((R >= 2 ? nout[2] : 0) + 1);
-    std::vector<Fp> prefix(nout[1] + 1);
-    const Aff<C>* in = in0.data();
+    auto tiles = [](uint32_t n_el) { return (size_t)(n_el + 63) / 64 + 1; };
+    std::vector<uint4> bufA(t64_bytes(tiles(nout[1]), T64_PT_CHUNKS) / 16), bufB(t64_bytes(tiles(R >= 2 ? nout[2] : 0), T64_PT_CHUNKS) / 16);
+    std::vector<uint4> prefix(t64_bytes(tiles(nout[1]), T64_FP_CHUNKS) / 16);
+    std::vector<uint4> st1(bufA.size()), st2(bufA.size());
+    const void* in = nullptr;
     *n_marks = 0;
     for (int r = 0; r < R; r++) {
         const uint32_t n_out = nout[r + 1];
-        Aff<C>* out = (r & 1) ? bufB.data() : bufA.data();
+        void* out = (r & 1) ? (void*)bufB.data() : (void*)bufA.data();
         if (n_out) {
             const uint32_t* st_in = r == 0 ? starts : st.data() + (size_t)(r - 1) * stride;
             const uint32_t* m_in = r == 0 ? counts : cnt.data() + (size_t)(r - 1) * stride;
             std::vector<uint32_t> desc(n_out);
             for (uint32_t o = 0; o < n_out; o++) desc[o] = aff_desc_body(st_in, m_in, st.data() + (size_t)r * stride, total, o);
             AffRoundArgs<C> a;
-            a.in = in; a.sorted = r == 0 ? sorted : nullptr; a.desc = desc.data(); a.n_out_p = &n_out;
-            a.prefix = prefix.data(); a.out = out; a.groups = waves * 64; a.bmin = bmin;
-            for (uint32_t t = 0; t < a.groups; t++) AffRoundLane<C, FS>::run(a, t, 0, true);
-            for (uint32_t o = 0; o < n_out; o++) if (out[o].x.l[0] == AFF_MARK) (*n_marks)++;
+            a.rows = in0.data(); a.in = in; a.sorted = r == 0 ? sorted : nullptr; a.desc = desc.data(); a.n_out_p = &n_out;
+            a.prefix = prefix.data(); a.out = out; a.stage1 = st1.data(); a.stage2 = st2.data(); a.groups = waves * 64; a.bmin = bmin;
+            for (uint32_t t = 0; t < a.groups; t++) {
+                if (r == 0) AffRoundLane<C, FS, true>::run(a, t, 0, true);
+                else AffRoundLane<C, FS, false>::run(a, t, 0, true);
+            }
+            for (uint32_t o = 0; o < n_out; o++) if (t64_ld_x(out, o >> 6, o & 63u).l[0] == AFF_MARK) (*n_marks)++;
         }
         in = out;
     }
@@ -56,7 +61,8 @@ static int run_tree(const uint64_t* bases_xy, size_t n_bases, const uint32_t* so
     for (uint32_t b = 0; b < total; b++) {
         Proj<C> acc = proj_zero<C>();
         for (uint32_t k = 0; k < mR[b]; k++) {
-            const Aff<C>& q = in[stR[b] + k];
+            const uint32_t e = stR[b] + k;
+            const Aff<C> q{t64_ld_x(in, e >> 6, e & 63u), t64_ld_y(in, e >> 6, e & 63u)};
             if (q.x.l[0] == AFF_MARK) continue;
             acc = proj_madd<C, typename C::F>(acc, q);
         }
