@@ -40,23 +40,40 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true", help="issue the steps one by one instead of as one pipelined batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ntt", action="store_true")
+    ap.add_argument("--curve", default="mnt4753_g1", choices=["mnt4753_g1", "mnt4753_g2", "mnt6753_g1", "mnt6753_g2"])
+    ap.add_argument("--total-log-n", type=int, default=0,
+                    help="strong scaling (BASELINE config 4): 2^total-log-n pairs in all, 2^total-log-n / N per GPU; overrides --log-n")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Started as a plain `python bench.py --gpus N`: become the launcher.  One rank per GPU is started as a child
+        # process tree (torch.distributed.run) BEFORE this process has touched the GPU; nothing is exec'ed over a
+        # process that has.
+        import socket
+        import subprocess
+        sock = socket.socket()
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+        sock.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but the launcher started %d rank(s)\n" % (args.gpus, world))
+        sys.exit(2)
     dist = None
-    device = None
-    backend = os.environ.get("GH_DIST_BACKEND", "nccl")   # "gloo" only to rehearse the N > 1 path on a one-GPU box
+    cdist = None
+    # Rendezvous, barrier and the max over ranks go over gloo (CPU); the data path -- the one exchange of partial sums --
+    # is the library's own RCCL communicator behind the C ABI (include/ginger_hip_dist.h), so torch's RCCL is never loaded.
+    # GH_DIST_BACKEND=gloo rehearses the N > 1 path on a one-GPU box (ranks share the card, the exchange goes over gloo).
+    backend = os.environ.get("GH_DIST_BACKEND", "rccl")
     if world > 1:
-        import torch
         import torch.distributed as dist
-        if backend == "nccl":
-            torch.cuda.set_device(local_rank)
-            device = torch.device("cuda", local_rank)
-            dist.init_process_group("nccl", device_id=device)
-        else:
-            dist.init_process_group(backend)
+        dist.init_process_group("gloo")
 
     import pyref
     from __graft_entry__ import _load_pkg
@@ -65,20 +82,33 @@ def main():
     distmod = importlib.import_module("ginger_lib_amd.dist")
     # raises if the HIP library or a gfx950 device is missing: no fallback.  (gloo rehearsal on a one-GPU
     # box: let the library map LOCAL_RANK modulo the device count.)
-    gl.init(local_rank if (world == 1 or backend == "nccl") else None)
+    gl.init(local_rank if (world == 1 or backend == "rccl") else None)
+    if world > 1:
+        if backend == "rccl":
+            from torch.distributed.distributed_c10d import _get_default_store
+            cdist = distmod.CDist(gl, rank, world, transport="rccl", store=_get_default_store())
+        else:
+            cdist = distmod.CDist(gl, rank, world, transport="callback", allgather=distmod.gloo_allgather_bytes(dist))
     if args.window:
         gl.msm_set_window(args.window)
 
-    curve = "mnt4753_g1"
+    curve = args.curve
     C = pyref.CURVES[curve]
-    n = 1 << args.log_n
+    strong = args.total_log_n > 0
+    if strong:
+        if (1 << args.total_log_n) % world:
+            sys.stderr.write("bench.py: 2^%d pairs do not split evenly over %d ranks\n" % (args.total_log_n, world))
+            sys.exit(2)
+        n = (1 << args.total_log_n) // world
+    else:
+        n = 1 << args.log_n
     # ---- synthetic inputs: distinct curve points along an addition chain (cofactor 1), tiled to n;
     #      scalars uniform in [0, r) with the reference's sampling shape, different per rank.
-    pool_n = min(n, 1 << 12)
+    pool_n = min(1 << (n.bit_length() - 1), 1 << (12 if C.deg == 1 else 9))
     import support as S     # helpers only (layout conversion); the oracle is used in cpu_baseline alone
     pool = S.chain_points(C, pool_n, pyref.Rng(1))
     pb, _ = S.bases_array(C, pool)
-    bases = np.tile(pb, (n // pool_n, 1))
+    bases = np.tile(pb, (-(-n // pool_n), 1))[:n]
     scalars = S.random_scalars_np(n, seed=1000 + rank, below=C.order)
     rb = gl.ResidentBases(curve, bases)
     ds = gl.DeviceBuffer(n * 96).upload(scalars)
@@ -101,7 +131,7 @@ def main():
         t0 = time.perf_counter()
         c_tab = rb.precompute(0)
         rows = 752 // c_tab + 1
-        table_info = {"window_bits": c_tab, "rows": rows, "bytes": rows * n * 208, "build_s": time.perf_counter() - t0,
+        table_info = {"window_bits": c_tab, "rows": rows, "bytes": rows * n * 208 * C.deg, "build_s": time.perf_counter() - t0,
                       "note": "one-time per resident key, outside the timed region (like the base upload)"}
         a1 = gl.proj_to_affine(curve, rb.msm_dev(ds, n))
         t0 = time.perf_counter()
@@ -128,16 +158,16 @@ def main():
         else:
             partials = gl.msm_batch_dev([(rb, ds, n)] * k)
             tms = [gl.msm_batch_timing(i) for i in range(k)]
-        totals = [distmod.all_gather_fold(p, proj_add, dist=dist, device=device) if world > 1 else p for p in partials]
+        totals = [cdist.allgather_fold(curve, p) if world > 1 else p for p in partials]
+        if world > 1:
+            exch_us.append(cdist.last_exchange_us)
         return totals, tms
 
+    exch_us = []
+
     def sync():
-        load = gl.load_library()
-        load.gh_dev_sync()
+        gl.load_library().gh_dev_sync()      # the library's streams (this process holds no other GPU work)
         if world > 1:
-            if device is not None:
-                import torch
-                torch.cuda.synchronize()
             dist.barrier()
 
     if args.warmup:
@@ -155,13 +185,14 @@ def main():
             phases[k] += t[k] / args.steps
     if world > 1:
         import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device if device is not None else "cpu")
+        t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     value = world * n * args.steps / elapsed
     tm_last = tm
     acc_avg_ms = float(np.mean(acc_ms))
-    alg_bytes = 288.0 * n                      # 288 B per G1 pair (192 B base + 96 B scalar), read once
+    # bytes per pair = affine base + 96-byte scalar, read once: G1 288 B, MNT4 G2 480 B, MNT6 G2 672 B
+    alg_bytes = (192.0 * C.deg + 96.0) * n
     achieved = alg_bytes / (acc_avg_ms * 1e-3) / 1e9
     madds = tm_last["accumulate_madds"]
     fpmul_rate = madds * 11 / (acc_avg_ms * 1e-3)
@@ -185,19 +216,22 @@ def main():
         "metric": "MNT4-753 G1 MSM scalar-muls/sec + 2^n NTT ms at 1/2/4/8 MI355X",
         "value": value,
         "unit": "scalar-muls/s",
-        "n_gpus": world,
+        "n_gpus": cdist.world_seen if cdist is not None else 1,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if strong else "weak",
         "vs_baseline": None,
         "dtype": "u32 (29-bit limbs of 753-bit Montgomery residues, 64-bit accumulators)",
         "data": "synthetic",
-        "config": {"workload": "MNT4-753 G1 VariableBaseMSM, 2^%d (base,scalar) pairs per GPU, bases+scalars resident in HBM" % args.log_n,
-                   "pairs_per_gpu": n, "window_bits": tm_last["window_bits"], "num_windows": tm_last["num_windows"],
+        "config": {"workload": "%s VariableBaseMSM, %s (base,scalar) pairs per GPU%s, bases+scalars resident in HBM" % (
+                       {"mnt4753_g1": "MNT4-753 G1", "mnt4753_g2": "MNT4-753 G2", "mnt6753_g1": "MNT6-753 G1", "mnt6753_g2": "MNT6-753 G2"}[curve],
+                       "2^%d" % (n.bit_length() - 1) if n & (n - 1) == 0 else str(n),
+                       " (2^%d in all, strong scaling)" % args.total_log_n if strong else ""),
+                   "curve": curve, "pairs_per_gpu": n, "window_bits": tm_last["window_bits"], "num_windows": tm_last["num_windows"],
                    "resident_key_shift_table": table_info, "distinct_bases": pool_n, "parallelism": "pairs sharded by rank, 1 all-gather of partial sums" if world > 1 else "single GPU"},
-        "roofline": {"kernel": "msm_accumulate_kernel<Mnt4G1>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+        "roofline": {"kernel": "msm_accumulate_kernel (bucket accumulation of the %s MSM)" % curve, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_acc,
                      "traffic_note": "FETCH_SIZE + WRITE_SIZE bytes per launch from profiles/r01_pmc_traffic.json (every pair is gathered once per window: W x 208 B; plus register-spill scratch)",
                      "avg_launch_ms": acc_avg_ms, "algorithmic_bytes_per_launch": alg_bytes,
@@ -209,6 +243,10 @@ def main():
                        "steps overlap (sort and reduce run beside the previous / next accumulation), so they do not add up to ms_per_step",
         "pipelined": not args.no_pipeline,
     }
+    if world > 1:
+        out["exchange"] = {"transport": "rccl all-gather behind gh_partials_allgather_fold" if backend == "rccl" else "gloo (rehearsal)",
+                           "ranks_seen_by_transport": cdist.world_seen, "bytes_per_rank": 288 * C.deg,
+                           "avg_us": float(np.mean(exch_us[-args.steps:])) if exch_us else None}
     if plain is not None:
         out["per_window_path"] = plain
         if not plain["same_affine_result_as_table_path"]:
@@ -289,6 +327,7 @@ def main():
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
+        cdist.shutdown()
         dist.destroy_process_group()
     if out.get("error"):
         sys.exit(1)

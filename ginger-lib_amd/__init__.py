@@ -29,13 +29,14 @@ FIELDS = {"mnt4753_fr": 0, "mnt6753_fr": 1}
 # every symbol include/ginger_hip.h declares (checked by load_library and by tests/test_abi.py)
 ABI_SYMBOLS = [
     "gh_init", "gh_shutdown", "gh_last_error", "gh_device_name",
-    "gh_msm", "gh_bases_upload", "gh_bases_upload_wire", "gh_bases_free", "gh_bases_len", "gh_bases_precompute", "gh_bases_precomputed_window",
+    "gh_msm", "gh_bases_upload", "gh_bases_upload_wire", "gh_bases_generate_chain", "gh_bases_download", "gh_bases_free", "gh_bases_len", "gh_bases_precompute", "gh_bases_precomputed_window",
     "gh_msm_resident", "gh_msm_resident_dev", "gh_msm_resident_dev_batch",
     "gh_msm_set_window", "gh_msm_set_affine", "gh_msm_get_window", "gh_msm_last_timing", "gh_msm_batch_timing",
     "gh_domain_supported", "gh_fft", "gh_fft_dev", "gh_vec_mul_dev", "gh_vec_sub_dev", "gh_vec_scale_dev",
     "gh_vec_mul", "gh_vec_scale", "gh_fft_last_kernel_ms", "gh_witness_map", "gh_witness_map_dev",
     "gh_dev_alloc", "gh_dev_free", "gh_dev_upload", "gh_dev_download", "gh_dev_sync", "gh_dev_trim",
     "gh_proj_add", "gh_proj_mul", "gh_proj_neg", "gh_proj_to_affine",
+    "gh_fixed_base_window", "gh_fixed_base_table", "gh_fixed_base_msm", "gh_fixed_base_free",
 ]
 # include/ginger_hip_dist.h
 DIST_SYMBOLS = ["gh_dist_unique_id", "gh_dist_init_rccl", "gh_dist_init_custom", "gh_dist_info", "gh_partials_allgather_fold",
@@ -75,6 +76,8 @@ def load_library():
     lib.gh_msm.argtypes = [ci, vp, vp, sz, vp, sz, vp]
     lib.gh_bases_upload.argtypes = [ci, vp, vp, sz, ctypes.POINTER(vp)]
     lib.gh_bases_upload_wire.argtypes = [ci, vp, sz, ctypes.POINTER(vp)]
+    lib.gh_bases_generate_chain.argtypes = [ci, vp, vp, sz, ctypes.POINTER(vp)]
+    lib.gh_bases_download.argtypes = [vp, sz, sz, vp]
     lib.gh_bases_free.argtypes = [vp]
     lib.gh_bases_len.argtypes = [vp]
     lib.gh_bases_len.restype = sz
@@ -107,6 +110,10 @@ def load_library():
     lib.gh_proj_mul.argtypes = [ci, vp, vp, vp]
     lib.gh_proj_neg.argtypes = [ci, vp]
     lib.gh_proj_to_affine.argtypes = [ci, vp, vp, vp]
+    lib.gh_fixed_base_window.argtypes = [sz]
+    lib.gh_fixed_base_table.argtypes = [ci, vp, sz, ci, ctypes.POINTER(vp)]
+    lib.gh_fixed_base_msm.argtypes = [vp, vp, sz, vp]
+    lib.gh_fixed_base_free.argtypes = [vp]
     lib.gh_dist_unique_id.argtypes = [vp]
     lib.gh_dist_init_rccl.argtypes = [vp, ci, ci]
     lib.gh_dist_init_custom.argtypes = [ALLGATHER_FN, vp, ci, ci]
@@ -206,6 +213,22 @@ class ResidentBases:
         _check(load_library().gh_bases_upload_wire(CURVES[curve], _ptr(buf), self.n, ctypes.byref(self.handle)))
         return self
 
+    @classmethod
+    def chain(cls, curve, p0_xy, step_xy, n):
+        """n distinct resident bases P_0 + i * H generated on the device (synthetic key: gh_bases_generate_chain)."""
+        self = cls.__new__(cls)
+        self.curve, self.n = curve, int(n)
+        self.handle = ctypes.c_void_p()
+        p0, st = _u64(p0_xy), _u64(step_xy)
+        _check(load_library().gh_bases_generate_chain(CURVES[curve], _ptr(p0), _ptr(st), self.n, ctypes.byref(self.handle)))
+        return self
+
+    def download(self, first, count):
+        """count x 24*deg u64: the resident bases [first, first + count) as Montgomery x || y rows"""
+        out = np.zeros((int(count), 24 * CURVE_DEG[self.curve]), dtype=np.uint64)
+        _check(load_library().gh_bases_download(self.handle, int(first), int(count), _ptr(out)))
+        return out
+
     def precompute(self, window_bits=0):
         """Build the per-key shift table (gh_bases_precompute); returns the window size used."""
         _check(load_library().gh_bases_precompute(self.handle, int(window_bits)))
@@ -262,6 +285,36 @@ class VariableBaseMSM:
         _check(load_library().gh_msm(CURVES[curve], _ptr(bases), _ptr(inf) if inf is not None else None, n_b,
                                       _ptr(scalars), n_s, _ptr(out)))
         return out
+
+
+class FixedBaseMSM:
+    """Mirror of algebra::msm::FixedBaseMSM (fixed_base.rs:7-79): get_mul_window_size / get_window_table /
+    multi_scalar_mul for one base g; the window table lives on the device."""
+
+    @staticmethod
+    def get_mul_window_size(num_scalars):
+        return load_library().gh_fixed_base_window(int(num_scalars))
+
+    def __init__(self, curve, g_xyz, scalar_size=753, window=None, num_scalars=0):
+        self.curve = curve
+        self.window = int(window) if window else self.get_mul_window_size(num_scalars)
+        g = _u64(g_xyz)
+        assert g.size == 36 * CURVE_DEG[curve]
+        self.handle = ctypes.c_void_p()
+        _check(load_library().gh_fixed_base_table(CURVES[curve], _ptr(g), int(scalar_size), self.window, ctypes.byref(self.handle)))
+
+    def multi_scalar_mul(self, scalars):
+        """scalars: n x 12 u64 canonical integers (into_repr); returns n x 36*deg u64 projective points"""
+        s = _u64(scalars, 12)
+        n = s.size // 12
+        out = np.zeros((n, 36 * CURVE_DEG[self.curve]), dtype=np.uint64)
+        _check(load_library().gh_fixed_base_msm(self.handle, _ptr(s), n, _ptr(out)))
+        return out
+
+    def free(self):
+        if self.handle:
+            load_library().gh_fixed_base_free(self.handle)
+            self.handle = ctypes.c_void_p()
 
 
 def msm_set_window(c):

@@ -12,6 +12,7 @@ namespace gh_rt {
 Ctx g;
 std::string g_err;
 static std::mutex g_mu;
+std::mutex& api_mutex() { return g_mu; }
 static char g_devname[256] = "";
 static int g_device_req = -1;   // gh_init(devices): explicit device index; -1 = $LOCAL_RANK (or 0)
 

@@ -14,6 +14,11 @@
 #define GH_F3S_TRIPLE 0   // Fq3 accumulation: 0 = three plain products in a rolled loop, 2 waves/SIMD; 1 = triple product with one
                          // reduction (fp_mul3, host-tested), unrolled, 1 wave/SIMD -- hipcc did not finish that kernel in 25 minutes
 #endif
+#ifndef GH_AFF_F3S_TRIPLE
+#define GH_AFF_F3S_TRIPLE 0   // Fq3 affine rounds: 1 = the three products of a lane as one triple product with a single reduction
+                              // (fp_mul3, 2704 mads instead of 4056) -- hipcc had not finished the two round kernels after 36
+                              // CPU-minutes; 0 = three plain products in a rolled loop
+#endif
 #ifndef GH_F2S_DUAL
 #define GH_F2S_DUAL 1   // Fq2 accumulation: 1 = dual product at 1 wave/SIMD (119 ms at 2^20 pairs); 0 = two plain products per
                         // lane at 2 waves/SIMD, measured 166 ms (1.8 KB of spills: both shuffled operand sets stay live)
@@ -122,7 +127,10 @@ inline int precompute_window(size_t n, int deg) {
     // (c = 17, 22) the top window's n digits land on 16 counters and the bucket sort's atomics
     // serialise (sort time x 2.5); c = 16 divides 752 and would add a carry-only window.
     int c;
-    if (deg > 1) c = lg <= 19 ? 18 : 21;
+    // G2: with the affine rounds the accumulation costs 6 tower products per addition instead of 11, while the bucket
+    // reduction (2^(c-1) buckets, projective) keeps its price: c = 21 at 2^20 pairs left 26 ms of reduction next to 80 ms
+    // of accumulation; c = 19 has a quarter of the buckets for 11 % more additions.
+    if (deg > 1) c = lg <= 19 ? 18 : (lg <= 22 ? 19 : 21);
     else if (lg <= 17) c = 18;
     else if (lg == 18) c = 20;
     else if (lg <= 22) c = 21;
@@ -378,7 +386,7 @@ struct MsmJob {
         {
             static const int env_aff = getenv("GH_AFFINE") ? atoi(getenv("GH_AFFINE")) : -1;
             const int mode = env_aff >= 0 ? env_aff : g.affine_mode;
-            tree = C::F::DEG == 1 && (mode == 1 || (mode == 2 && (size_t)W * n >= ((size_t)1 << 21)));
+            tree = mode == 1 || (mode == 2 && (size_t)W * n >= ((size_t)1 << 21));
         }
         // salt points S0 = G, S1 = 2G (internal affine form) for the accumulate kernel's detour
         static Aff<C>* d_salts = nullptr;
@@ -477,7 +485,7 @@ struct MsmJob {
             HIPCHK(hipMemsetAsync((void*)(buckets + total), 0, (slots - total) * sizeof(Proj<C>), st));
         HIPCHK(hipEventRecord(g.pev[slot][2], st));
         if (tree) {   // may clear `tree` when its scratch does not fit next to the key: the projective kernel takes over
-            if constexpr (C::F::DEG == 1) { if ((rc = launch_tree(st))) return rc; }
+            if ((rc = launch_tree(st))) return rc;
         }
         if (!tree) {
         {
@@ -524,8 +532,14 @@ struct MsmJob {
 
     // Bucket sums by affine rounds (aff_kernels.h) on stream st: plan (per-round bucket sizes and offsets: R small
     // scans), R rounds (descriptor kernel + round kernel), then the projective kernel over what is left per bucket.
+    // lane-group field of the rounds: one lane per element (G1), lane pairs with the dual product (Fq2), lane triples with
+    // the single-reduction triple product (Fq3: six product sites per addition, where the projective kernel's eleven did
+    // not get through hipcc unrolled)
+    typedef typename std::conditional<C::F::DEG == 1, F1S<typename C::PF>,
+            typename std::conditional<C::F::DEG == 2, F2S<P4, 13, true>, F3S<P6, 11, GH_AFF_F3S_TRIPLE != 0>>::type>::type TreeFS;
+
     int launch_tree(hipStream_t st) {
-        typedef F1S<typename C::PF> FS;
+        typedef TreeFS FS;
         constexpr int LANES = FS::LANES;
         constexpr uint32_t TPW = 64 / LANES;
         int rc;
@@ -609,11 +623,20 @@ struct MsmJob {
             doff += n_out;
             in = out;
         }
-        // what is left (about two points per bucket): projective, one bucket per thread, longest first
-        hipLaunchKernelGGL((msm_accumulate_kernel<C, 2, true>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const Aff<C>*)in,
-                           (const uint32_t*)nullptr, (const uint32_t*)(aff_st + (size_t)(R - 1) * stride),
-                           (const uint32_t*)(aff_cnt + (size_t)(R - 1) * stride), (const uint32_t*)order, (uint32_t)total,
-                           (const Aff<C>*)salts, buckets, (const uint32_t*)chunk_start, 0u, 0u, heavy_chunk, (Proj<C>*)nullptr);
+        // what is left (a few points per bucket): projective, one bucket per thread / lane group, longest first
+        if constexpr (C::F::DEG == 1) {
+            hipLaunchKernelGGL((msm_accumulate_kernel<C, 2, true>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const Aff<C>*)in,
+                               (const uint32_t*)nullptr, (const uint32_t*)(aff_st + (size_t)(R - 1) * stride),
+                               (const uint32_t*)(aff_cnt + (size_t)(R - 1) * stride), (const uint32_t*)order, (uint32_t)total,
+                               (const Aff<C>*)salts, buckets, (const uint32_t*)chunk_start, 0u, 0u, heavy_chunk, (Proj<C>*)nullptr);
+        } else {
+            typedef typename std::conditional<C::F::DEG == 2, F2S<P4, 13, GH_F2S_DUAL != 0>, F3S<P6, 11, GH_F3S_TRIPLE != 0>>::type FA;
+            const size_t fwaves = (total + TPW - 1) / TPW;
+            hipLaunchKernelGGL((msm_accumulate_split_kernel<C, FA, LANES, true>), dim3((unsigned)((fwaves * 64 + 255) / 256)), dim3(256), 0, st,
+                               (const Aff<C>*)in, (const uint32_t*)nullptr, (const uint32_t*)(aff_st + (size_t)(R - 1) * stride),
+                               (const uint32_t*)(aff_cnt + (size_t)(R - 1) * stride), (const uint32_t*)order, (uint32_t)total,
+                               (const Aff<C>*)salts, buckets, (const uint32_t*)chunk_start, 0u, 0u, heavy_chunk, (Proj<C>*)nullptr);
+        }
         n_heavy = 0;   // no chunk sums to combine
         return GH_OK;
     }

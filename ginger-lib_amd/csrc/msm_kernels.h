@@ -566,6 +566,16 @@ template <class P, int NR, bool DUAL = true> struct F2S {
     }
     static __device__ __forceinline__ T mul_sub_mul(const T& a, const T& b, const T& c, const T& d) { return sub(mul(a, b), mul(c, d)); }
     static __device__ __forceinline__ T sqr(const T& a) { return mul(a, a); }
+    // (the dual product takes fully reduced operands only: (3 p^2 + R p) / R > 2p with a lazy one)
+    static __device__ __forceinline__ T sub_lazy(const T& a, const T& b) { return fp_sub<P>(a, b); }
+    // (a0 + a1 X)^-1 = (a0 - a1 X) / (a0^2 - NR a1^2)     (fp2.rs inverse): one Fp inversion per lane pair, run by both lanes
+    static __device__ __forceinline__ T inv(const T& a) {
+        const bool o = odd();
+        const T s = fp_sqr<P>(a), t = swap(s);                       // own square, the partner's
+        const T n = o ? fp_sub<P>(t, fp_mul_small<P, NR>(s)) : fp_sub<P>(s, fp_mul_small<P, NR>(t));
+        const T r = fp_mul<P>(a, fp_inv<P>(n));
+        return o ? fp_neg<P>(r) : r;
+    }
     static __device__ __forceinline__ bool is_zero(const T& a) {
         const int z = fp_is_zero(a) ? 1 : 0;
         return (z & __shfl_xor(z, 1)) != 0;
@@ -642,6 +652,27 @@ template <class P, int NR, bool TRIPLE = false> struct F3S {
     }
     static __device__ __forceinline__ T sqr(const T& a) { return mul(a, a); }
     static __device__ __forceinline__ T mul_sub_mul(const T& a, const T& b, const T& c, const T& d) { return sub(mul(a, b), mul(c, d)); }
+    static __device__ __forceinline__ T sub_lazy(const T& a, const T& b) { return fp_sub<P>(a, b); }   // triple / rolled products: reduced operands
+    // norm-based inverse in Fp[X]/(X^3 - NR) (fp3.rs inverse), one Fp inversion per lane triple:
+    //   c0 = a0^2 - NR a1 a2,  c1 = NR a2^2 - a0 a1,  c2 = a1^2 - a0 a2,  n = a0 c0 + NR (a2 c1 + a1 c2),  a^-1 = c / n
+    // lane j holds a_j: it forms its own square and the product a_j a_(j+1), the rest travels by lane rotation.
+    static __device__ __forceinline__ T inv(const T& a) {
+        const int j = comp();
+        const T a1 = rot(a, 1), a2 = rot(a, 2);                      // a_(j+1), a_(j+2)
+        const T sq = fp_sqr<P>(a), pr = fp_mul<P>(a, a1);            // a_j^2, a_j a_(j+1):  pr = (a0 a1, a1 a2, a2 a0)
+        const T sq1 = rot(sq, 1), sq2 = rot(sq, 2), pr1 = rot(pr, 1), pr2 = rot(pr, 2);
+        // c_j:  j = 0: sq_0 - NR pr_1     j = 1: NR sq_2 - pr_0     j = 2: sq_1 - pr_2
+        const T u = j == 0 ? sq : (j == 1 ? fp_mul_small<P, NR>(sq1) : sq2);      // lane 1: sq_2 = sq_(j+1); lane 2: sq_1 = sq_(j+2)
+        const T v = j == 0 ? fp_mul_small<P, NR>(pr1) : (j == 1 ? pr2 : pr);      // lane 0: pr_1; lane 1: pr_0 = pr_(j+2); lane 2: pr_2 = own
+        const T c = fp_sub<P>(u, v);
+        // n = a0 c0 + NR (a2 c1 + a1 c2): lane j multiplies c_j by a_0, a_2, a_1
+        const T q = fp_mul<P>(j == 0 ? a : (j == 1 ? a1 : a2), c);  // lane 1: a_2 = a_(j+1); lane 2: a_1 = a_(j+2)
+        const T q1 = rot(q, 1), q2 = rot(q, 2);
+        const T q0v = j == 0 ? q : (j == 1 ? q2 : q1);              // q_0 as seen from lane j
+        const T qs = j == 0 ? fp_add<P>(q1, q2) : (j == 1 ? fp_add<P>(q, q1) : fp_add<P>(q2, q));   // q_1 + q_2
+        const T n = fp_add<P>(q0v, fp_mul_small<P, NR>(qs));
+        return fp_mul<P>(c, fp_inv<P>(n));
+    }
     static __device__ __forceinline__ bool all3(bool z) {
         const int lane = threadIdx.x & 63, j = lane % 3, b = lane - j;
         const int v = z ? 1 : 0;
@@ -656,7 +687,8 @@ template <class P, int NR, bool TRIPLE = false> struct F3S {
 #ifndef GH_SPLIT_WAVES
 #define GH_SPLIT_WAVES 1   // measured on Fq2 (twice): 119 ms at 1 wave/SIMD (512 registers) vs 135 ms at 2 (1.5 KB of spills), 2^20 pairs
 #endif
-template <class C, class F, int LANES>
+// AFFIN: as for msm_accumulate_kernel -- the input is the T64 output list of the affine rounds.
+template <class C, class F, int LANES, bool AFFIN = false>
 __global__ void __launch_bounds__(256, F::WAVES)
 msm_accumulate_split_kernel(const Aff<C>* __restrict__ bases, const uint32_t* __restrict__ sorted,
                            const uint32_t* __restrict__ starts, const uint32_t* __restrict__ counts,
@@ -702,6 +734,13 @@ msm_accumulate_split_kernel(const Aff<C>* __restrict__ bases, const uint32_t* __
             qx = ld_comp(salts + salt_id, 0);
             qy = ld_comp(salts + salt_id, 1);
             if (phase == 3) qy = F::neg(qy);
+        } else if constexpr (AFFIN) {
+            const uint32_t e = beg + k;
+            const size_t tile = e / TPW;
+            const uint32_t slot = (e % TPW) * LANES + (uint32_t)comp;
+            qx = t64_ld_x(bases, tile, slot);
+            qy = t64_ld_y(bases, tile, slot);
+            if (phase == 0 && k < cnt && qx.l[0] == AFF_MARK) { k++; continue; }   // a cancelled pair (every lane of the group sees the marker)
         } else {
             const uint32_t e = sorted[beg + k];
             const Aff<C>* b = bases + (e & 0x7FFFFFFFu);

@@ -51,6 +51,7 @@ extern Ctx g;
 extern std::string g_err;
 
 int ensure_init();
+std::mutex& api_mutex();     // the lock every ABI entry point holds (one device context per process)
 int pool_get(const char* name, size_t bytes, void** out);
 int device_scan(const uint32_t* in, uint32_t* out, size_t n, const char* tmpname, hipStream_t stream = nullptr);   // nullptr: g.stream
 int auto_window(size_t n, int deg);

@@ -98,6 +98,12 @@ int gh_bases_upload(gh_curve_t curve, const uint64_t* bases, const uint8_t* infi
  * i.e. 193 / 385 / 577 bytes per G1 / MNT4-G2 / MNT6-G2 point.  GH_E_BAD_ARG where FromBytes would fail
  * (a coefficient >= p, a flag byte other than 0 / 1).                                                  */
 int gh_bases_upload_wire(gh_curve_t curve, const uint8_t* bytes, size_t n_points, gh_bases_t* out_handle);
+/* Synthetic key (benchmarks, full-size tests): n distinct resident bases P_i = P_0 + i * H along
+ * an addition chain, generated on the device from two affine points (x || y, Montgomery).  Both curves' G1 have
+ * cofactor 1 and multiples of the G2 generator stay in the subgroup, so every P_i is a valid base.        */
+int gh_bases_generate_chain(gh_curve_t curve, const uint64_t* p0_xy, const uint64_t* step_xy, size_t n, gh_bases_t* out_handle);
+/* Copy `count` resident bases starting at `first` back to the host (x || y Montgomery limbs, as gh_bases_upload takes them). */
+int gh_bases_download(gh_bases_t handle, size_t first, size_t count, uint64_t* out_xy);
 int gh_bases_free(gh_bases_t handle);
 size_t gh_bases_len(gh_bases_t handle);
 /* Optional, once per resident key: build the shift table 2^(c w) P_i, w = 0 .. floor(752/c), in
@@ -123,6 +129,23 @@ int gh_msm_resident_dev(gh_bases_t handle, const void* d_scalars, size_t n_scala
  * accumulation of MSM i.  handles may repeat; results do not depend on the batching.           */
 int gh_msm_resident_dev_batch(const gh_bases_t* handles, const void* const* d_scalars, const size_t* n_scalars, int count,
                               uint64_t* out_xyz);
+
+/* ---- fixed-base multi-scalar multiplication --------------------------------------------------
+ * FixedBaseMSM (algebra/src/msm/fixed_base.rs:7-79): out[i] = scalars[i] * g for ONE base g, through a window
+ * table of g -- what the Groth16 parameter generator spends its time in (proof-systems/src/groth16/generator.rs:
+ * 225-296: every query of the proving key is one such call).
+ *   gh_fixed_base_window  = FixedBaseMSM::get_mul_window_size(num_scalars)                          (:7-13)
+ *   gh_fixed_base_table   = get_window_table(scalar_size, window, g): g projective (ABI format), kept on the
+ *                           device in affine form, ceil(scalar_size / window) rows of 2^window points (:15-43)
+ *   gh_fixed_base_msm     = multi_scalar_mul(scalar_size, window, table, v): scalars are CANONICAL integers
+ *                           (v[i].into_repr(), 12 u64 each), out_xyz receives n projective points (3 * 12 * deg
+ *                           u64 each).  Same group elements as the reference; as there, only into_affine() of a
+ *                           result is canonical.                                                    (:45-78) */
+typedef struct gh_fixed_table* gh_fixed_table_t;
+int gh_fixed_base_window(size_t num_scalars);
+int gh_fixed_base_table(gh_curve_t curve, const uint64_t* g_xyz, size_t scalar_size, int window, gh_fixed_table_t* out_table);
+int gh_fixed_base_msm(gh_fixed_table_t table, const uint64_t* scalars, size_t n, uint64_t* out_xyz);
+int gh_fixed_base_free(gh_fixed_table_t table);
 
 /* Window size override for sweeps (0 = automatic).  Affects subsequent MSM calls. */
 int gh_msm_set_window(int c);

@@ -488,6 +488,54 @@ Projective<C> msm_inner(const Affine<C>* bases, size_t n_bases, const Big* scala
     return total;
 }
 
+// ---- msm/fixed_base.rs:7-79  FixedBaseMSM (literal restatement)
+static inline size_t fixed_base_window_size(size_t num_scalars) {                                          // get_mul_window_size :7-13
+    if (num_scalars < 32) return 3;
+    return (size_t)std::ceil(std::log((double)(uint32_t)num_scalars));                                     // ln, as u32
+}
+template <class C>
+std::vector<std::vector<Projective<C>>> fixed_base_window_table(size_t scalar_size, size_t window, Projective<C> g) {   // :15-43
+    typedef Projective<C> T;
+    const size_t in_window = (size_t)1 << window;
+    const size_t outerc = (scalar_size + window - 1) / window;
+    const size_t last_in_window = (size_t)1 << (scalar_size - (outerc - 1) * window);
+    std::vector<std::vector<T>> multiples_of_g(outerc, std::vector<T>(in_window, T::zero()));
+    T g_outer = g;
+    for (size_t outer = 0; outer < outerc; outer++) {
+        T g_inner = T::zero();
+        const size_t cur_in_window = outer == outerc - 1 ? last_in_window : in_window;
+        for (size_t inner = 0; inner < cur_in_window; inner++) {
+            multiples_of_g[outer][inner] = g_inner;
+            g_inner.add_assign(g_outer);
+        }
+        for (size_t k = 0; k < window; k++) g_outer.double_in_place();
+    }
+    return multiples_of_g;
+}
+template <class C, class ScalarP>
+Projective<C> fixed_base_windowed_mul(size_t outerc, size_t window, const std::vector<std::vector<Projective<C>>>& table,
+                                      const Fp<ScalarP>& scalar) {                                          // :45-66
+    const Big repr = scalar.into_repr();                        // to_bits() reversed = little-endian bit order
+    Projective<C> res = table[0][0];
+    for (size_t outer = 0; outer < outerc; outer++) {
+        size_t inner = 0;
+        for (size_t i = 0; i < window; i++) {
+            const size_t bit = outer * window + i;
+            if (bit < 753 && ((repr.l[bit / 64] >> (bit % 64)) & 1)) inner |= (size_t)1 << i;               // MODULUS_BITS = 753
+        }
+        res.add_assign(table[outer][inner]);
+    }
+    return res;
+}
+template <class C, class ScalarP>
+std::vector<Projective<C>> fixed_base_msm(size_t scalar_size, size_t window, const std::vector<std::vector<Projective<C>>>& table,
+                                          const Fp<ScalarP>* v, size_t n, int threads) {                   // :68-78
+    const size_t outerc = (scalar_size + window - 1) / window;
+    std::vector<Projective<C>> out(n, Projective<C>::zero());
+    parallel_for(n, threads, [&](size_t i) { out[i] = fixed_base_windowed_mul<C, ScalarP>(outerc, window, table, v[i]); });
+    return out;
+}
+
 // ---- fft/domain.rs
 template <class P> struct Domain {
     typedef Fp<P> F;

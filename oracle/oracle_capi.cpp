@@ -56,6 +56,18 @@ int msm_c(const uint64_t* bases, const uint8_t* infinity, size_t n_bases, const 
     return 0;
 }
 
+// FixedBaseMSM::multi_scalar_mul over the window table of g (fixed_base.rs): scalars are Montgomery field elements
+// (T::ScalarField), out = n projective points; window == 0: get_mul_window_size(n).  Returns the window used.
+template <class C, class SP>
+int fixed_c(const uint64_t* g_xyz, size_t scalar_size, size_t window, const uint64_t* scalars, size_t n, uint64_t* out_xyz, int threads) {
+    if (window == 0) window = fixed_base_window_size(n);
+    Projective<C> g = rd_proj<C>(g_xyz);
+    auto table = fixed_base_window_table<C>(scalar_size, window, g);
+    auto res = fixed_base_msm<C, SP>(scalar_size, window, table, reinterpret_cast<const Fp<SP>*>(scalars), n, threads);
+    for (size_t i = 0; i < n; i++) wr_proj<C>(out_xyz + i * 36 * C::DEG, res[i]);
+    return (int)window;
+}
+
 // op: 0 add (proj+proj) 1 double 2 mixed add (q affine, q_inf flag in `flag`) 3 scalar mul by canonical k (in q)
 //     4 into_affine (out = x||y, returns infinity flag) 5 projective equality (returns 0/1)
 template <class C> int ec_c(int op, const uint64_t* p, const uint64_t* q, int flag, uint64_t* out) {
@@ -141,6 +153,16 @@ int oracle_msm(int curve, const uint64_t* bases, const uint8_t* infinity, size_t
         case 1: return msm_c<Mnt4G2, P6>(bases, infinity, n_bases, scalars, n_scalars, out_xyz, threads);
         case 2: return msm_c<Mnt6G1, P4>(bases, infinity, n_bases, scalars, n_scalars, out_xyz, threads);
         case 3: return msm_c<Mnt6G2, P4>(bases, infinity, n_bases, scalars, n_scalars, out_xyz, threads);
+    }
+    return -1;
+}
+int oracle_fixed_base_msm(int curve, const uint64_t* g_xyz, size_t scalar_size, size_t window, const uint64_t* scalars, size_t n,
+                          uint64_t* out_xyz, int threads) {
+    switch (curve) {
+        case 0: return fixed_c<Mnt4G1, P6>(g_xyz, scalar_size, window, scalars, n, out_xyz, threads);
+        case 1: return fixed_c<Mnt4G2, P6>(g_xyz, scalar_size, window, scalars, n, out_xyz, threads);
+        case 2: return fixed_c<Mnt6G1, P4>(g_xyz, scalar_size, window, scalars, n, out_xyz, threads);
+        case 3: return fixed_c<Mnt6G2, P4>(g_xyz, scalar_size, window, scalars, n, out_xyz, threads);
     }
     return -1;
 }

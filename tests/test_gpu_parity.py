@@ -409,7 +409,8 @@ def test_msm_batch_pipelined(gpu):
         rb.free()
 
 
-@pytest.mark.parametrize("curve,n,windows", [("mnt4753_g1", 3000, (0, 9, 13)), ("mnt6753_g1", 700, (0, 12))])
+@pytest.mark.parametrize("curve,n,windows", [("mnt4753_g1", 3000, (0, 9, 13)), ("mnt6753_g1", 700, (0, 12)),
+                                             ("mnt4753_g2", 640, (0, 9)), ("mnt6753_g2", 620, (0, 8))])
 def test_msm_affine_bucket_sums_vs_oracle(gpu, curve, n, windows):
     """gh_msm_set_affine(1): bucket sums by affine rounds (aff_kernels.h: pairwise rounds over the flat list, batched
     safegcd inversion).  Duplicate and opposite bases in one bucket (doubling / cancellation handled in the round),
@@ -454,7 +455,7 @@ def test_msm_affine_bucket_sums_vs_oracle(gpu, curve, n, windows):
         rb.free()
 
 
-@pytest.mark.parametrize("curve", ["mnt4753_g1", "mnt6753_g1"])
+@pytest.mark.parametrize("curve", ["mnt4753_g1", "mnt6753_g1", "mnt4753_g2", "mnt6753_g2"])
 def test_msm_affine_degenerate_inputs(gpu, curve):
     """affine rounds on inputs made of the group law's special cases only: all bases equal (every addition of every
     round is a doubling), bases in opposite pairs with equal scalars (every bucket cancels to infinity), a single pair,
