@@ -172,8 +172,10 @@ template <class C> struct AffRoundArgs {
     const Aff<C>* rows;        // round 0: the bases / the shift table, row-major (sorted != nullptr)
     const void* in;            // later rounds: the previous round's output, T64 (sorted == nullptr)
     const uint32_t* sorted;    // round 0: list entries (row index | sign << 31); nullptr afterwards
-    const uint32_t* desc;      // per output element: first input index | pair << 31
-    const uint32_t* n_out_p;   // number of output elements (device memory: the host only has a bound)
+    const uint32_t* desc;      // per output element of this launch: first input index (global) | pair << 31
+    uint32_t n_out;            // output elements of this launch (one chunk of buckets, one round)
+    uint32_t in_base;          // global index of the chunk's first input element in the previous round's list (the T64 lists
+                               // of a chunk start at 0)
     void* prefix;              // running products, T64 (one tile per wave iteration)
     void* out;                 // this round's output list, T64
     void *stage1, *stage2;     // round 0: the two inputs of every output element as gathered by the forward pass (signs
@@ -296,7 +298,7 @@ template <class C, class FS, bool R0> struct AffRoundLane {
                 r1 = act ? a.sorted[ai] : 0u;
                 r2 = pair ? a.sorted[ai + 1] : 0u;
             } else {
-                r1 = ai; r2 = ai + 1;
+                r1 = act ? ai - a.in_base : 0u; r2 = r1 + 1;
             }
         }
         GH_HD Elem decode(uint32_t de, bool act, uint32_t r1, uint32_t r2) const {
@@ -338,7 +340,7 @@ template <class C, class FS, bool R0> struct AffRoundLane {
 #endif
 
     GH_HD static void run(const AffRoundArgs<C>& a, uint32_t t, int comp, bool live) {
-        const uint32_t n_out = *a.n_out_p;
+        const uint32_t n_out = a.n_out;
         uint32_t B = (n_out + a.groups - 1) / a.groups;
         if (B < a.bmin) B = a.bmin;
         const uint32_t wv = t / TPW, g = t % TPW;
@@ -480,20 +482,35 @@ aff_counts_kernel(const uint32_t* __restrict__ counts, uint32_t total, int R, si
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b < total) aff_counts_body(counts, b, R, stride, cnt);
 }
-// n_out[r] = st[last] + m[last] of round r's list (r = 1 .. R), n_out[0] = entries of the sorted list
-static __global__ void aff_totals_kernel(const uint32_t* __restrict__ starts, const uint32_t* __restrict__ counts,
-                                         const uint32_t* __restrict__ st, const uint32_t* __restrict__ cnt, uint32_t total,
-                                         int R, size_t stride, uint32_t* __restrict__ n_out) {
-    const int r = threadIdx.x;
-    if (r == 0) n_out[0] = starts[total - 1] + counts[total - 1];
-    else if (r <= R) n_out[r] = st[(size_t)(r - 1) * stride + total - 1] + cnt[(size_t)(r - 1) * stride + total - 1];
-}
+// descriptors of the outputs [o_base, o_base + n_out) of a round (one chunk of buckets), stored chunk-relative
 static __global__ void __launch_bounds__(256)
 aff_desc_kernel(const uint32_t* __restrict__ st_in, const uint32_t* __restrict__ m_in, const uint32_t* __restrict__ st_out,
-                uint32_t total, const uint32_t* __restrict__ n_out_p, uint32_t* __restrict__ desc) {
-    const uint32_t n_out = *n_out_p;
+                uint32_t total, uint32_t o_base, uint32_t n_out, uint32_t* __restrict__ desc) {
     for (uint32_t o = blockIdx.x * blockDim.x + threadIdx.x; o < n_out; o += gridDim.x * blockDim.x)
-        desc[o] = aff_desc_body(st_in, m_in, st_out, total, o);
+        desc[o] = aff_desc_body(st_in, m_in, st_out, total, o_base + o);
+}
+// Chunks of buckets with about equal numbers of list entries (the scratch lists of the rounds are sized per chunk):
+// bq[j] = first bucket of chunk j (bq[K] = total); tab[j * (R + 1) + r] = global index of chunk j's first element in
+// round r's list (row K: the list lengths).
+static __global__ void aff_chunks_kernel(const uint32_t* __restrict__ starts, const uint32_t* __restrict__ counts,
+                                         const uint32_t* __restrict__ st, const uint32_t* __restrict__ cnt, uint32_t total, int R,
+                                         size_t stride, uint32_t K, uint32_t* __restrict__ bq, uint32_t* __restrict__ tab) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j > K) return;
+    const uint32_t n0 = starts[total - 1] + counts[total - 1];
+    uint32_t b = total;
+    if (j < K) {
+        const uint32_t target = (uint32_t)(((uint64_t)n0 * j) / K);
+        uint32_t lo = 0, hi = total;     // first bucket with starts[b] >= target
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (starts[mid] < target) lo = mid + 1; else hi = mid; }
+        b = lo;
+    }
+    bq[j] = b;
+    for (int r = 0; r <= R; r++) {
+        const uint32_t* s_r = r == 0 ? starts : st + (size_t)(r - 1) * stride;
+        const uint32_t* m_r = r == 0 ? counts : cnt + (size_t)(r - 1) * stride;
+        tab[(size_t)j * (R + 1) + r] = b < total ? s_r[b] : s_r[total - 1] + m_r[total - 1];
+    }
 }
 
 template <class C, class FS, bool R0>

@@ -63,6 +63,22 @@ int pool_get(const char* name, size_t bytes, void** out) {
     return GH_OK;
 }
 
+size_t pool_cap(const char* name) {
+    auto it = g.pool.find(name);
+    return it == g.pool.end() ? 0 : it->second.cap;
+}
+void pool_release(const char* prefix) {
+    const size_t len = strlen(prefix);
+    for (auto it = g.pool.begin(); it != g.pool.end();) {
+        if (it->first.compare(0, len, prefix) == 0) {
+            if (it->second.p) (void)hipFree(it->second.p);
+            it = g.pool.erase(it);
+        } else {
+            ++it;
+        }
+    }
+}
+
 // generic exclusive scan of n u32 on the library stream
 int device_scan(const uint32_t* in, uint32_t* out, size_t n, const char* tmpname, hipStream_t stream) {
     using namespace gh;
@@ -499,8 +515,7 @@ int gh_dev_trim(void) {
     HIPCHK(hipStreamSynchronize(g.stream));
     HIPCHK(hipStreamSynchronize(g.stream_acc));
     HIPCHK(hipStreamSynchronize(g.stream_red));
-    for (auto& kv : g.pool) if (kv.second.p) hipFree(kv.second.p);
-    g.pool.clear();
+    pool_release("");
     return GH_OK;
 }
 int gh_dev_sync(void) {

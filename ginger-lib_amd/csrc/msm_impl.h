@@ -152,6 +152,13 @@ int precompute_bases(BasesBase* h, int c_req) {
     HIPCHK(hipMemGetInfo(&free_b, &total_b));
     const size_t slab = n < ((size_t)1 << 20) ? n : ((size_t)1 << 20);
     const size_t need = (size_t)W * n * sizeof(Aff<C>) + 2 * (size_t)(W - 1) * slab * sizeof(FT) + ((size_t)1 << 30);
+    if (need > free_b) {   // the scratch caches of earlier calls (bucket lists, affine-round lists) are only caches: drop them
+        HIPCHK(hipStreamSynchronize(g.stream));
+        HIPCHK(hipStreamSynchronize(g.stream_acc));
+        HIPCHK(hipStreamSynchronize(g.stream_red));
+        pool_release("");
+        HIPCHK(hipMemGetInfo(&free_b, &total_b));
+    }
     if (need > free_b) { g_err = "not enough device memory for the precomputed table"; return GH_E_NOMEM; }
     Aff<C>* table = nullptr;
     FT *zs = nullptr, *zp = nullptr;
@@ -565,21 +572,56 @@ struct MsmJob {
     if ((rc = pool_get(nm, bytes, (void**)&ptr))) return rc;
         POOLT("aff_cnt", aff_cnt, (size_t)R * stride * 4)
         POOLT("aff_st", aff_st, (size_t)R * stride * 4)
-        POOLT("aff_nout", aff_nout, (AFF_MAX_ROUNDS + 2) * 4)
         hipLaunchKernelGGL(aff_counts_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
                            (const uint32_t*)counts, (uint32_t)total, R, stride, aff_cnt);
         snprintf(nm, sizeof nm, "aff_scan#%d", slot);
         for (int r = 1; r <= R; r++)
             if ((rc = device_scan(aff_cnt + (size_t)(r - 1) * stride, aff_st + (size_t)(r - 1) * stride, total, nm, st))) return rc;
-        hipLaunchKernelGGL(aff_totals_kernel, dim3(1), dim3(64), 0, st, (const uint32_t*)starts, (const uint32_t*)counts,
-                           (const uint32_t*)aff_st, (const uint32_t*)aff_cnt, (uint32_t)total, R, stride, aff_nout);
+        // Chunks of buckets: the scratch lists of the rounds are sized per chunk, so that a 2^24-pair key (or a G2 key with
+        // its shift table) does not need 300 GB of them.  ~420 bytes x lanes per list entry: the staged inputs, the two
+        // output lists, the running products and the descriptors of a chunk.
+        static const double env_scratch_gb = getenv("GH_AFF_SCRATCH_GB") ? atof(getenv("GH_AFF_SCRATCH_GB")) : 20.0;
+        uint32_t K = 1;
+        {
+            size_t free_b = 0, total_b = 0;
+            HIPCHK(hipMemGetInfo(&free_b, &total_b));
+            size_t have = 0;
+            const char* names[6] = {"aff_desc", "aff_ptsA", "aff_ptsB", "aff_prefix", "aff_stage1", "aff_stage2"};
+            for (int i = 0; i < 6; i++) { snprintf(nm, sizeof nm, "%s#%d", names[i], slot); have += pool_cap(nm); }
+            double budget = env_scratch_gb * 1073741824.0;
+            const double avail = ((double)free_b + (double)have - 3.0 * 1073741824.0) * 0.9;     // what this slot may hold at most
+            if (budget > avail) budget = avail;
+            const double need = 430.0 * LANES * (double)n0 * 1.13;                                // incl. the pool's 1/8 slack
+            if (budget < 256.0 * 1048576.0) {       // no room at all: the projective kernel runs
+                for (int i = 0; i < 6; i++) { snprintf(nm, sizeof nm, "%s#%d", names[i], slot); pool_release(nm); }
+                tree = false;
+                return GH_OK;
+            }
+            while ((double)K * budget < need && K < 4096) K++;
+        }
+        uint32_t *d_bq, *d_tab;
+        POOLT("aff_bq", d_bq, ((size_t)K + 2) * 4)
+        POOLT("aff_tab", d_tab, ((size_t)K + 2) * (R + 1) * 4)
+        hipLaunchKernelGGL(aff_chunks_kernel, dim3((K + 1 + 63) / 64), dim3(64), 0, st, (const uint32_t*)starts, (const uint32_t*)counts,
+                           (const uint32_t*)aff_st, (const uint32_t*)aff_cnt, (uint32_t)total, R, stride, K, d_bq, d_tab);
         HIPCHK(hipGetLastError());
-        uint32_t* hn = hplan + 16;   // n_0 .. n_R
-        HIPCHK(hipMemcpyAsync(hn, aff_nout, (size_t)(R + 1) * 4, hipMemcpyDeviceToHost, st));
+        std::vector<uint32_t> bq((size_t)K + 1), tab(((size_t)K + 1) * (R + 1));
+        HIPCHK(hipMemcpyAsync(bq.data(), d_bq, bq.size() * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(tab.data(), d_tab, tab.size() * 4, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
-        if (hn[0] != n0) { g_err = "internal: affine plan disagrees with the sort stage"; return GH_E_HIP; }
-        size_t n_desc = 0;
-        for (int r = 1; r <= R; r++) n_desc += hn[r];
+        auto T = [&](uint32_t j, int r) { return tab[(size_t)j * (R + 1) + r]; };
+        if (T(K, 0) != n0) { g_err = "internal: affine plan disagrees with the sort stage"; return GH_E_HIP; }
+        // the largest chunk sizes every list
+        uint32_t max_n1 = 0, max_n2 = 0;
+        size_t max_desc = 0;
+        for (uint32_t j = 0; j < K; j++) {
+            const uint32_t n1 = T(j + 1, 1) - T(j, 1), n2 = R >= 2 ? T(j + 1, 2) - T(j, 2) : 0;
+            if (n1 > max_n1) max_n1 = n1;
+            if (n2 > max_n2) max_n2 = n2;
+            size_t dsum = 0;
+            for (int r = 1; r <= R; r++) dsum += T(j + 1, r) - T(j, r);
+            if (dsum > max_desc) max_desc = dsum;
+        }
         uint32_t* desc;
         void *ptsA, *ptsB, *prefix, *stage1, *stage2;     // T64 lists (aff_kernels.h)
         auto tiles = [&](uint32_t n_el) { return ((size_t)n_el + TPW - 1) / TPW + 1; };
@@ -589,54 +631,58 @@ struct MsmJob {
     rc = pool_get(nm, bytes, (void**)&ptr);                         \
     if (rc == GH_E_NOMEM) { (void)hipGetLastError(); tree = false; return GH_OK; } \
     if (rc) return rc;
-        POOLBIG("aff_desc", desc, (n_desc + 64) * 4)
-        POOLBIG("aff_ptsA", ptsA, t64_bytes(tiles(hn[1]), T64_PT_CHUNKS))
-        POOLBIG("aff_ptsB", ptsB, t64_bytes(tiles(R >= 2 ? hn[2] : 0), T64_PT_CHUNKS))
-        POOLBIG("aff_prefix", prefix, t64_bytes(tiles(hn[1]), T64_FP_CHUNKS))
-        POOLBIG("aff_stage1", stage1, t64_bytes(tiles(hn[1]), T64_PT_CHUNKS))
-        POOLBIG("aff_stage2", stage2, t64_bytes(tiles(hn[1]), T64_PT_CHUNKS))
+        POOLBIG("aff_desc", desc, (max_desc + 64) * 4)
+        POOLBIG("aff_ptsA", ptsA, t64_bytes(tiles(max_n1), T64_PT_CHUNKS))
+        POOLBIG("aff_ptsB", ptsB, t64_bytes(tiles(max_n2), T64_PT_CHUNKS))
+        POOLBIG("aff_prefix", prefix, t64_bytes(tiles(max_n1), T64_FP_CHUNKS))
+        POOLBIG("aff_stage1", stage1, t64_bytes(tiles(max_n1), T64_PT_CHUNKS))
+        POOLBIG("aff_stage2", stage2, t64_bytes(tiles(max_n1), T64_PT_CHUNKS))
 #undef POOLBIG
         const uint32_t max_waves = (uint32_t)g.num_cus * 4u * (uint32_t)FS::WAVES;
-        size_t doff = 0;
         const Aff<C>* rows = (const Aff<C>*)(merged ? h->d_table : h->d_points);
-        const void* in = nullptr;
-        for (int r = 0; r < R; r++) {
-            const uint32_t n_out = hn[r + 1];
-            void* out = (r & 1) ? ptsB : ptsA;
-            if (n_out > 0) {
-                const uint32_t* st_in = r == 0 ? starts : aff_st + (size_t)(r - 1) * stride;
-                const uint32_t* m_in = r == 0 ? counts : aff_cnt + (size_t)(r - 1) * stride;
-                unsigned dgrid = (n_out + 255) / 256;
-                if (dgrid > 16384) dgrid = 16384;
-                hipLaunchKernelGGL(aff_desc_kernel, dim3(dgrid), dim3(256), 0, st, st_in, m_in,
-                                   (const uint32_t*)(aff_st + (size_t)r * stride), (uint32_t)total,
-                                   (const uint32_t*)(aff_nout + r + 1), desc + doff);
-                uint32_t waves = (n_out + TPW * (uint32_t)env_bmin - 1) / (TPW * (uint32_t)env_bmin);
-                if (waves > max_waves) waves = max_waves;
-                waves = (waves + 3u) & ~3u;
-                AffRoundArgs<C> a;
-                a.rows = rows; a.in = in; a.sorted = r == 0 ? sorted : nullptr; a.desc = desc + doff; a.n_out_p = aff_nout + r + 1;
-                a.prefix = prefix; a.out = out; a.stage1 = stage1; a.stage2 = stage2; a.groups = waves * TPW; a.bmin = (uint32_t)env_bmin;
-                if (r == 0) hipLaunchKernelGGL((aff_round_kernel<C, FS, true>), dim3(waves / 4), dim3(256), 0, st, a);
-                else hipLaunchKernelGGL((aff_round_kernel<C, FS, false>), dim3(waves / 4), dim3(256), 0, st, a);
+        for (uint32_t j = 0; j < K; j++) {
+            size_t doff = 0;
+            const void* in = nullptr;
+            for (int r = 0; r < R; r++) {
+                const uint32_t n_out = T(j + 1, r + 1) - T(j, r + 1);
+                void* out = (r & 1) ? ptsB : ptsA;
+                if (n_out > 0) {
+                    const uint32_t* st_in = r == 0 ? starts : aff_st + (size_t)(r - 1) * stride;
+                    const uint32_t* m_in = r == 0 ? counts : aff_cnt + (size_t)(r - 1) * stride;
+                    unsigned dgrid = (n_out + 255) / 256;
+                    if (dgrid > 16384) dgrid = 16384;
+                    hipLaunchKernelGGL(aff_desc_kernel, dim3(dgrid), dim3(256), 0, st, st_in, m_in,
+                                       (const uint32_t*)(aff_st + (size_t)r * stride), (uint32_t)total, T(j, r + 1), n_out, desc + doff);
+                    uint32_t waves = (n_out + TPW * (uint32_t)env_bmin - 1) / (TPW * (uint32_t)env_bmin);
+                    if (waves > max_waves) waves = max_waves;
+                    waves = (waves + 3u) & ~3u;
+                    AffRoundArgs<C> a;
+                    a.rows = rows; a.in = in; a.sorted = r == 0 ? sorted : nullptr; a.desc = desc + doff; a.n_out = n_out; a.in_base = T(j, r);
+                    a.prefix = prefix; a.out = out; a.stage1 = stage1; a.stage2 = stage2; a.groups = waves * TPW; a.bmin = (uint32_t)env_bmin;
+                    if (r == 0) hipLaunchKernelGGL((aff_round_kernel<C, FS, true>), dim3(waves / 4), dim3(256), 0, st, a);
+                    else hipLaunchKernelGGL((aff_round_kernel<C, FS, false>), dim3(waves / 4), dim3(256), 0, st, a);
+                }
+                doff += n_out;
+                in = out;
             }
-            doff += n_out;
-            in = out;
+            // what is left of the chunk's buckets (a few points each): projective, one bucket per thread / lane group
+            const uint32_t nbk = bq[j + 1] - bq[j];
+            if (nbk == 0) continue;
+            const uint32_t* stR = aff_st + (size_t)(R - 1) * stride;
+            const uint32_t* mR = aff_cnt + (size_t)(R - 1) * stride;
+            if constexpr (C::F::DEG == 1) {
+                hipLaunchKernelGGL((msm_accumulate_kernel<C, 2, true>), dim3((nbk + 255) / 256), dim3(256), 0, st, (const Aff<C>*)in,
+                                   (const uint32_t*)nullptr, stR, mR, (const uint32_t*)nullptr, nbk, (const Aff<C>*)salts, buckets,
+                                   (const uint32_t*)nullptr, 0u, 0u, heavy_chunk, (Proj<C>*)nullptr, bq[j], T(j, R));
+            } else {
+                typedef typename std::conditional<C::F::DEG == 2, F2S<P4, 13, GH_F2S_DUAL != 0>, F3S<P6, 11, GH_F3S_TRIPLE != 0>>::type FA;
+                const size_t fwaves = ((size_t)nbk + TPW - 1) / TPW;
+                hipLaunchKernelGGL((msm_accumulate_split_kernel<C, FA, LANES, true>), dim3((unsigned)((fwaves * 64 + 255) / 256)), dim3(256), 0, st,
+                                   (const Aff<C>*)in, (const uint32_t*)nullptr, stR, mR, (const uint32_t*)nullptr, nbk, (const Aff<C>*)salts, buckets,
+                                   (const uint32_t*)nullptr, 0u, 0u, heavy_chunk, (Proj<C>*)nullptr, bq[j], T(j, R));
+            }
         }
-        // what is left (a few points per bucket): projective, one bucket per thread / lane group, longest first
-        if constexpr (C::F::DEG == 1) {
-            hipLaunchKernelGGL((msm_accumulate_kernel<C, 2, true>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const Aff<C>*)in,
-                               (const uint32_t*)nullptr, (const uint32_t*)(aff_st + (size_t)(R - 1) * stride),
-                               (const uint32_t*)(aff_cnt + (size_t)(R - 1) * stride), (const uint32_t*)order, (uint32_t)total,
-                               (const Aff<C>*)salts, buckets, (const uint32_t*)chunk_start, 0u, 0u, heavy_chunk, (Proj<C>*)nullptr);
-        } else {
-            typedef typename std::conditional<C::F::DEG == 2, F2S<P4, 13, GH_F2S_DUAL != 0>, F3S<P6, 11, GH_F3S_TRIPLE != 0>>::type FA;
-            const size_t fwaves = (total + TPW - 1) / TPW;
-            hipLaunchKernelGGL((msm_accumulate_split_kernel<C, FA, LANES, true>), dim3((unsigned)((fwaves * 64 + 255) / 256)), dim3(256), 0, st,
-                               (const Aff<C>*)in, (const uint32_t*)nullptr, (const uint32_t*)(aff_st + (size_t)(R - 1) * stride),
-                               (const uint32_t*)(aff_cnt + (size_t)(R - 1) * stride), (const uint32_t*)order, (uint32_t)total,
-                               (const Aff<C>*)salts, buckets, (const uint32_t*)chunk_start, 0u, 0u, heavy_chunk, (Proj<C>*)nullptr);
-        }
+        HIPCHK(hipGetLastError());
         n_heavy = 0;   // no chunk sums to combine
         return GH_OK;
     }

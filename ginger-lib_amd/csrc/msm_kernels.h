@@ -409,7 +409,7 @@ msm_accumulate_kernel(const Aff<C>* __restrict__ bases, const uint32_t* __restri
                       const uint32_t* __restrict__ order, uint32_t total,
                       const Aff<C>* __restrict__ salts, Proj<C>* __restrict__ buckets,
                       const uint32_t* __restrict__ chunk_start, uint32_t n_heavy, uint32_t n_chunks, uint32_t chunk,
-                      Proj<C>* __restrict__ partials) {
+                      Proj<C>* __restrict__ partials, uint32_t g_first = 0, uint32_t list_base = 0) {
     typedef typename C::F F;
     // task list: [0, n_chunks) chunks of the heavy buckets (the longest tasks, scheduled first),
     //            then the buckets order[n_heavy ..] by descending size
@@ -417,7 +417,11 @@ msm_accumulate_kernel(const Aff<C>* __restrict__ bases, const uint32_t* __restri
     if (t >= n_chunks + (total - n_heavy)) return;
     uint32_t beg, cnt;
     Proj<C>* dst;
-    if (t >= n_chunks) {         // one whole bucket per thread
+    if constexpr (AFFIN) {       // bucket g_first + t of a chunk of buckets; its points sit at starts[g] - list_base of the chunk's list
+        const uint32_t g = g_first + t;
+        beg = starts[g] - list_base; cnt = counts[g];
+        dst = buckets + g;
+    } else if (t >= n_chunks) {         // one whole bucket per thread
         const uint32_t g = order[n_heavy + (t - n_chunks)];
         beg = starts[g]; cnt = counts[g];
         dst = buckets + g;
@@ -695,7 +699,7 @@ msm_accumulate_split_kernel(const Aff<C>* __restrict__ bases, const uint32_t* __
                            const uint32_t* __restrict__ order, uint32_t total,
                            const Aff<C>* __restrict__ salts, Proj<C>* __restrict__ buckets,
                            const uint32_t* __restrict__ chunk_start, uint32_t n_heavy, uint32_t n_chunks, uint32_t chunk,
-                           Proj<C>* __restrict__ partials) {
+                           Proj<C>* __restrict__ partials, uint32_t g_first = 0, uint32_t list_base = 0) {
     constexpr uint32_t TPW = 64 / LANES;                       // tasks per wave
     const uint32_t lane = threadIdx.x & 63u, wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t t = wave * TPW + lane / LANES;
@@ -705,7 +709,11 @@ msm_accumulate_split_kernel(const Aff<C>* __restrict__ bases, const uint32_t* __
     uint32_t beg = 0, cnt = 0;
     Proj<C>* dst = buckets;
     if (live) {
-        if (t >= n_chunks) {
+        if constexpr (AFFIN) {
+            const uint32_t g = g_first + t;
+            beg = starts[g] - list_base; cnt = counts[g];
+            dst = buckets + g;
+        } else if (t >= n_chunks) {
             const uint32_t g = order[n_heavy + (t - n_chunks)];
             beg = starts[g]; cnt = counts[g];
             dst = buckets + g;

@@ -53,6 +53,8 @@ extern std::string g_err;
 int ensure_init();
 std::mutex& api_mutex();     // the lock every ABI entry point holds (one device context per process)
 int pool_get(const char* name, size_t bytes, void** out);
+size_t pool_cap(const char* name);                 // current capacity of a cached buffer (0 if none)
+void pool_release(const char* prefix);             // free every cached buffer whose name starts with prefix ("" = all)
 int device_scan(const uint32_t* in, uint32_t* out, size_t n, const char* tmpname, hipStream_t stream = nullptr);   // nullptr: g.stream
 int auto_window(size_t n, int deg);
 

@@ -45,7 +45,7 @@ static int run_tree(const uint64_t* bases_xy, size_t n_bases, const uint32_t* so
             std::vector<uint32_t> desc(n_out);
             for (uint32_t o = 0; o < n_out; o++) desc[o] = aff_desc_body(st_in, m_in, st.data() + (size_t)r * stride, total, o);
             AffRoundArgs<C> a;
-            a.rows = in0.data(); a.in = in; a.sorted = r == 0 ? sorted : nullptr; a.desc = desc.data(); a.n_out_p = &n_out;
+            a.rows = in0.data(); a.in = in; a.sorted = r == 0 ? sorted : nullptr; a.desc = desc.data(); a.n_out = n_out; a.in_base = 0;
             a.prefix = prefix.data(); a.out = out; a.stage1 = st1.data(); a.stage2 = st2.data(); a.groups = waves * 64; a.bmin = bmin;
             for (uint32_t t = 0; t < a.groups; t++) {
                 if (r == 0) AffRoundLane<C, FS, true>::run(a, t, 0, true);

@@ -153,16 +153,14 @@ def test_split_kernels_heavy_buckets_batch_vs_oracle(gpu, curve, log_n):
         for table in (False, True):
             if table:
                 rb.precompute(0)
-            assert affine(gpu, curve, rb.msm_dev(ds, n)) == exp_s, (curve, table)
-            if not table:
-                assert gpu.msm_last_timing()["heavy_buckets"] > 0 or C.deg == 1
-            outs = gpu.msm_batch_dev([(rb, ds, n), (rb, dt, n), (rb, ds, half), (rb, dt, n)])
-            got = [affine(gpu, curve, o) for o in outs]
-            assert got == [exp_s, exp_t, exp_h, exp_t], (curve, table)
-        if True:                  # both forms of the bucket sums on the same skewed input (table path)
-            for mode in (0, 1):
+            for mode in (0, 1):       # projective bucket sums (heavy buckets cut into chunks) and affine rounds (extra rounds)
                 gpu.msm_set_affine(mode)
-                assert affine(gpu, curve, rb.msm_dev(ds, n)) == exp_s, (curve, "affine mode", mode)
+                assert affine(gpu, curve, rb.msm_dev(ds, n)) == exp_s, (curve, table, mode)
+                if mode == 0 and not table:
+                    assert gpu.msm_last_timing()["heavy_buckets"] > 0
+                outs = gpu.msm_batch_dev([(rb, ds, n), (rb, dt, n), (rb, ds, half), (rb, dt, n)])
+                got = [affine(gpu, curve, o) for o in outs]
+                assert got == [exp_s, exp_t, exp_h, exp_t], (curve, table, mode)
     finally:
         gpu.msm_set_affine(2)
         ds.free(); dt.free()
