@@ -23,6 +23,18 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
+def kernels_sha():
+    """sha256 over the device sources: stamps profiles/*_pmc_traffic.json so that stale counters are not reported"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "ginger-lib_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".h", ".hip")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()
+
+
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 measured)
 FPMUL_PEAK_PER_S = 23.4e9       # measured 753-bit Montgomery products/s, profiles/r01_microbench_valu_rates.txt
 
@@ -40,6 +52,7 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true", help="issue the steps one by one instead of as one pipelined batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ntt", action="store_true")
+    ap.add_argument("--no-2p24", action="store_true", help="skip the extra 2^24-pair object (BASELINE config 3's second size)")
     ap.add_argument("--curve", default="mnt4753_g1", choices=["mnt4753_g1", "mnt4753_g2", "mnt6753_g1", "mnt6753_g2"])
     ap.add_argument("--total-log-n", type=int, default=0,
                     help="strong scaling (BASELINE config 4): 2^total-log-n pairs in all, 2^total-log-n / N per GPU; overrides --log-n")
@@ -102,15 +115,19 @@ def main():
         n = (1 << args.total_log_n) // world
     else:
         n = 1 << args.log_n
-    # ---- synthetic inputs: distinct curve points along an addition chain (cofactor 1), tiled to n;
+    # ---- synthetic inputs: n DISTINCT bases P_0 + i H along an addition chain, generated on the device
+    #      (gh_bases_generate_chain: every G1 point is a valid base, multiples of the G2 generator stay in the subgroup);
     #      scalars uniform in [0, r) with the reference's sampling shape, different per rank.
-    pool_n = min(1 << (n.bit_length() - 1), 1 << (12 if C.deg == 1 else 9))
     import support as S     # helpers only (layout conversion); the oracle is used in cpu_baseline alone
-    pool = S.chain_points(C, pool_n, pyref.Rng(1))
-    pb, _ = S.bases_array(C, pool)
-    bases = np.tile(pb, (-(-n // pool_n), 1))[:n]
+
+    def chain_key(crv, count, seed):
+        Cc = pyref.CURVES[crv]
+        prng = pyref.Rng(seed)
+        xy, _ = S.bases_array(Cc, [Cc.mul(prng.next_u64() | 1, Cc.G), Cc.mul(prng.next_u64() | 1, Cc.G)])
+        return gl.ResidentBases.chain(crv, xy[0], xy[1], count)
+
+    rb = chain_key(curve, n, 1 + rank)
     scalars = S.random_scalars_np(n, seed=1000 + rank, below=C.order)
-    rb = gl.ResidentBases(curve, bases)
     ds = gl.DeviceBuffer(n * 96).upload(scalars)
     # The bases are a proving key: uploaded once, outside the timed region, and -- like the
     # layout conversion at upload -- expanded once into the shift table 2^(c w) P_i (gh_bases_precompute).
@@ -170,6 +187,9 @@ def main():
         if world > 1:
             dist.barrier()
 
+    # which accumulation the library's automatic policy picked for this curve (include/ginger_hip.h: gh_msm_set_affine)
+    bucket_mode = "affine rounds (aff_kernels.h) + projective finish" if (C.deg > 1 and os.environ.get("GH_AFFINE", "2") != "0") or os.environ.get("GH_AFFINE") == "1" \
+        else "projective mixed additions"
     if args.warmup:
         run_steps(args.warmup)
     sync()
@@ -195,20 +215,25 @@ def main():
     alg_bytes = (192.0 * C.deg + 96.0) * n
     achieved = alg_bytes / (acc_avg_ms * 1e-3) / 1e9
     madds = tm_last["accumulate_madds"]
-    fpmul_rate = madds * 11 / (acc_avg_ms * 1e-3)
+    # base-field products per addition: projective mixed addition 11 (madd-1998-cmo); affine rounds 5 M + 1 S (+ the shared
+    # inversion, not counted); tower fields: Fq2 product = 4 Fp products in the lane-pair form, Fq3 = 9
+    per_add = (6 if bucket_mode.startswith("affine") else 11) * {1: 1, 2: 4, 3: 9}[C.deg]
+    fpmul_rate = madds * per_add / (acc_avg_ms * 1e-3)
 
     # HBM traffic per launch of the dominant kernels: PMC counters collected with rocprofv3 in separate
     # passes on this same command (profiles/r01_pmc_traffic.json); null if that file is absent or the
     # workload differs from the profiled one (2^20 pairs / 2^24 points).
     traffic_acc = traffic_ntt = None
+    traffic_src = "profiles/r02_pmc_traffic.json"
     try:
-        tr = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-        ent = tr["msm_accumulate_kernel"] if tm_last["window_bits"] == tr["msm_accumulate_kernel"]["window_bits"] else \
-            tr["msm_accumulate_kernel_per_window_path"]
-        if args.log_n == 20 and ent["window_bits"] == tm_last["window_bits"]:
-            traffic_acc = ent["fetch_bytes_per_launch"] + ent["write_bytes_per_launch"]
-        if args.ntt_log_n == 24:
-            traffic_ntt = tr["ntt_pass_kernel"]["fetch_bytes_per_transform"] + tr["ntt_pass_kernel"]["write_bytes_per_transform"]
+        tr = json.load(open(os.path.join(ROOT, traffic_src)))
+        if tr.get("kernels_sha256") == kernels_sha():          # counters go stale when the kernels change: then null
+            ent = tr.get("%s_2p%d" % (curve, n.bit_length() - 1))
+            if ent and ent["window_bits"] == tm_last["window_bits"] and ent["bucket_sums"] == bucket_mode:
+                traffic_acc = ent["fetch_bytes_per_msm"] + ent["write_bytes_per_msm"]
+            ent = tr.get("ntt_2p%d" % args.ntt_log_n)
+            if ent:
+                traffic_ntt = ent["fetch_bytes_per_transform"] + ent["write_bytes_per_transform"]
     except Exception:
         pass
 
@@ -230,14 +255,15 @@ def main():
                        "2^%d" % (n.bit_length() - 1) if n & (n - 1) == 0 else str(n),
                        " (2^%d in all, strong scaling)" % args.total_log_n if strong else ""),
                    "curve": curve, "pairs_per_gpu": n, "window_bits": tm_last["window_bits"], "num_windows": tm_last["num_windows"],
-                   "resident_key_shift_table": table_info, "distinct_bases": pool_n, "parallelism": "pairs sharded by rank, 1 all-gather of partial sums" if world > 1 else "single GPU"},
+                   "resident_key_shift_table": table_info, "distinct_bases": n, "bucket_sums": bucket_mode, "parallelism": "pairs sharded by rank, 1 all-gather of partial sums" if world > 1 else "single GPU"},
         "roofline": {"kernel": "msm_accumulate_kernel (bucket accumulation of the %s MSM)" % curve, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_acc,
-                     "traffic_note": "FETCH_SIZE + WRITE_SIZE bytes per launch from profiles/r01_pmc_traffic.json (every pair is gathered once per window: W x 208 B; plus register-spill scratch)",
+                     "traffic_note": "FETCH_SIZE + WRITE_SIZE bytes of the accumulation launches of one MSM from %s (separate rocprofv3 --pmc passes), null when that file was measured on other kernel sources (sha256 of ginger-lib_amd/csrc) or another workload" % traffic_src,
                      "avg_launch_ms": acc_avg_ms, "algorithmic_bytes_per_launch": alg_bytes,
                      "note": "integer-VALU bound by construction (SURVEY 8d): see valu"},
         "valu": {"achieved_fpmul_per_s": fpmul_rate, "peak_fpmul_per_s": FPMUL_PEAK_PER_S, "frac": fpmul_rate / FPMUL_PEAK_PER_S,
-                 "note": "11 Fp-mul per mixed addition; peak = measured rr29 Montgomery-product microbenchmark"},
+                 "fp_products_per_addition": per_add,
+                 "note": "peak = measured rr29 Montgomery-product microbenchmark (profiles/r01_microbench_valu_rates.txt)"},
         "phases_ms": phases,
         "phases_note": "per-MSM device phases by HIP events on their streams; with the pipelined batch the phases of neighbouring "
                        "steps overlap (sort and reduce run beside the previous / next accumulation), so they do not add up to ms_per_step",
@@ -251,6 +277,47 @@ def main():
         out["per_window_path"] = plain
         if not plain["same_affine_result_as_table_path"]:
             out["error"] = "table path and per-window path disagree"
+
+    # ---- BASELINE config 3's second size: 2^24 pairs (per-window path and shift table c = 23, 115 GB), same line
+    if not args.no_2p24 and rank == 0 and world == 1 and curve == "mnt4753_g1" and not args.window and args.log_n < 24:
+        try:
+            n24 = 1 << 24
+            rb24 = chain_key(curve, n24, 77)
+            s24 = S.random_scalars_np(n24, seed=2024, below=C.order)
+            d24 = gl.DeviceBuffer(n24 * 96).upload(s24)
+            del s24
+            rb24.msm_dev(d24, n24)
+            t1 = time.perf_counter()
+            p_out = rb24.msm_dev(d24, n24)
+            pw_ms = (time.perf_counter() - t1) * 1e3
+            ptm = gl.msm_last_timing()
+            t1 = time.perf_counter()
+            c24 = rb24.precompute(0)
+            build_s = time.perf_counter() - t1
+            rb24.msm_dev(d24, n24)
+            t1 = time.perf_counter()
+            t_out = rb24.msm_dev(d24, n24)
+            tb_ms = (time.perf_counter() - t1) * 1e3
+            ttm = gl.msm_last_timing()
+            t1 = time.perf_counter()
+            gl.msm_batch_dev([(rb24, d24, n24)] * 3)
+            bt_ms = (time.perf_counter() - t1) * 1e3 / 3
+            a0, a1 = gl.proj_to_affine(curve, p_out), gl.proj_to_affine(curve, t_out)
+            out["msm_2p24"] = {
+                "workload": "MNT4-753 G1 VariableBaseMSM, 2^24 distinct pairs, resident",
+                "per_window_path": {"value": n24 / pw_ms * 1e3, "ms": pw_ms, "window_bits": ptm["window_bits"], "num_windows": ptm["num_windows"],
+                                    "accumulate_ms": ptm["accumulate_ms"]},
+                "shift_table": {"value": n24 / tb_ms * 1e3, "ms": tb_ms, "window_bits": c24, "rows": 752 // c24 + 1,
+                                "bytes": (752 // c24 + 1) * n24 * 208, "build_s": build_s, "accumulate_ms": ttm["accumulate_ms"],
+                                "pipelined_batch_of_3": {"value": n24 / bt_ms * 1e3, "ms_per_msm": bt_ms}},
+                "unit": "scalar-muls/s", "same_affine_result": bool(a0[1] == a1[1] and (a0[0] == a1[0]).all())}
+            if not out["msm_2p24"]["same_affine_result"]:
+                out["error"] = "2^24: table path and per-window path disagree"
+            d24.free()
+            rb24.free()
+            gl.dev_trim()
+        except gl.GingerHipError as e:          # e.g. not enough HBM next to another tenant: the object is absent, the line stands
+            out["msm_2p24"] = {"error": str(e)}
 
     # ---- NTT (single GPU per rank; reported from rank 0)
     if not args.no_ntt and rank == 0:
@@ -283,6 +350,7 @@ def main():
         import math
         c_ref = 3 if m < 32 else math.ceil(2.0 / 3.0 * math.log2(m) + 2.0)      # variable_base.rs:14-18
         msm_threads = min(cores, -(-753 // c_ref))                               # one task per window (:30-31)
+        bases = rb.download(0, m)                                                # the first m resident bases, Montgomery rows
         t1 = time.perf_counter()
         exp = S.oracle_msm(curve, bases[:m], None, scalars[:m], msm_threads)
         cpu_s = time.perf_counter() - t1

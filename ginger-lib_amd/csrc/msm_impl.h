@@ -388,12 +388,16 @@ struct MsmJob {
             g_err = "MSM too large for 31-bit list entries";
             return GH_E_UNSUPPORTED;
         }
-        // Bucket sums by affine rounds (aff_kernels.h): g.affine_mode 0 = never, 1 = always, 2 = when the list is long
-        // enough to fill the chip (each round costs at least one inversion's latency, ~0.3 ms).
+        // Bucket sums by affine rounds (aff_kernels.h): g.affine_mode 0 = never, 1 = always, 2 = where they are measured
+        // faster: on G2 (6 tower products per addition instead of 11: MNT4 G2 2^20 119 -> 80 ms, MNT6 G2 2^19 200 -> 130 ms)
+        // once the list is long enough to fill the chip (a round costs at least one inversion's latency, ~0.3 ms).  On G1
+        // the rounds tie with the projective kernel alone (22.9 vs 22.6 ms at 2^20: 0.7 x the instructions, but round 0 is
+        // bound by its table gathers and every round pays an inversion per lane) and lose inside a pipelined batch
+        // (30.4 vs 28.0 ms per MSM), so G1 stays projective unless asked.
         {
             static const int env_aff = getenv("GH_AFFINE") ? atoi(getenv("GH_AFFINE")) : -1;
             const int mode = env_aff >= 0 ? env_aff : g.affine_mode;
-            tree = mode == 1 || (mode == 2 && (size_t)W * n >= ((size_t)1 << 21));
+            tree = mode == 1 || (mode == 2 && C::F::DEG >= 2 && (size_t)W * n >= ((size_t)1 << 21));
         }
         // salt points S0 = G, S1 = 2G (internal affine form) for the accumulate kernel's detour
         static Aff<C>* d_salts = nullptr;

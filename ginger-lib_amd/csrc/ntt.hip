@@ -79,7 +79,9 @@ template <class P> int get_domain(int fidx, int log_n, bool need_coset, bool nee
     return GH_OK;
 }
 
-template <class P> int fft_run(int fidx, void* d_data, uint32_t log_n, uint32_t flags) {
+// sync = false: the caller (witness_map) issues several transforms and pointwise kernels back to back on the library
+// stream and waits once at the end
+template <class P> int fft_run(int fidx, void* d_data, uint32_t log_n, uint32_t flags, bool sync = true) {
     if ((int)log_n >= FieldConsts<P>::two_adicity) {
         g_err = "domain exceeds the field's 2-adicity";
         return GH_E_UNSUPPORTED;
@@ -135,12 +137,14 @@ template <class P> int fft_run(int fidx, void* d_data, uint32_t log_n, uint32_t 
     HIPCHK(hipGetLastError());
     if (cur == 1) HIPCHK(hipMemcpyAsync(d_data, d->scratch, ((size_t)96) << log_n, hipMemcpyDeviceToDevice, g.stream));
     HIPCHK(hipEventRecord(g.ev[5], g.stream));
-    HIPCHK(hipStreamSynchronize(g.stream));
-    HIPCHK(hipEventElapsedTime(&g.last_fft_ms, g.ev[4], g.ev[5]));
+    if (sync) {
+        HIPCHK(hipStreamSynchronize(g.stream));
+        HIPCHK(hipEventElapsedTime(&g.last_fft_ms, g.ev[4], g.ev[5]));
+    }
     return GH_OK;
 }
 
-template <class P> int vec_op(int op, void* d_a, const void* d_b, const uint64_t* scalar12, size_t n) {
+template <class P> int vec_op(int op, void* d_a, const void* d_b, const uint64_t* scalar12, size_t n, bool sync = true) {
     if (n == 0) return GH_OK;
     Fp s = fp_zero();
     if (op == 2) s = fp_from_abi<P>(reinterpret_cast<const uint32_t*>(scalar12));
@@ -149,7 +153,7 @@ template <class P> int vec_op(int op, void* d_a, const void* d_b, const uint64_t
     else if (op == 1) hipLaunchKernelGGL((vec_op_kernel<P, 1>), grid, blk, 0, g.stream, (uint32_t*)d_a, (const uint32_t*)d_b, s, n);
     else hipLaunchKernelGGL((vec_op_kernel<P, 2>), grid, blk, 0, g.stream, (uint32_t*)d_a, (const uint32_t*)d_b, s, n);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(g.stream));
+    if (sync) HIPCHK(hipStreamSynchronize(g.stream));
     return GH_OK;
 }
 
@@ -160,14 +164,14 @@ template <class P> int witness_map_t(int fidx, void* d_a, void* d_b, void* d_c, 
     const size_t N = (size_t)1 << log_n;
     int rc;
     // a, b -> coefficients -> evaluations on the coset (:121-122, :134-135)
-    if ((rc = fft_run<P>(fidx, d_a, log_n, GH_FFT_INVERSE))) return rc;
-    if ((rc = fft_run<P>(fidx, d_b, log_n, GH_FFT_INVERSE))) return rc;
-    if ((rc = fft_run<P>(fidx, d_a, log_n, GH_FFT_COSET))) return rc;
-    if ((rc = fft_run<P>(fidx, d_b, log_n, GH_FFT_COSET))) return rc;
-    if ((rc = vec_op<P>(0, d_a, d_b, nullptr, N))) return rc;                        // ab = a .* b (:137)
-    if ((rc = fft_run<P>(fidx, d_c, log_n, GH_FFT_INVERSE))) return rc;              // :153
-    if ((rc = fft_run<P>(fidx, d_c, log_n, GH_FFT_COSET))) return rc;                // :154
-    if ((rc = vec_op<P>(1, d_a, d_c, nullptr, N))) return rc;                        // ab -= c (:156-158)
+    if ((rc = fft_run<P>(fidx, d_a, log_n, GH_FFT_INVERSE, false))) return rc;
+    if ((rc = fft_run<P>(fidx, d_b, log_n, GH_FFT_INVERSE, false))) return rc;
+    if ((rc = fft_run<P>(fidx, d_a, log_n, GH_FFT_COSET, false))) return rc;
+    if ((rc = fft_run<P>(fidx, d_b, log_n, GH_FFT_COSET, false))) return rc;
+    if ((rc = vec_op<P>(0, d_a, d_b, nullptr, N, false))) return rc;                        // ab = a .* b (:137)
+    if ((rc = fft_run<P>(fidx, d_c, log_n, GH_FFT_INVERSE, false))) return rc;              // :153
+    if ((rc = fft_run<P>(fidx, d_c, log_n, GH_FFT_COSET, false))) return rc;                // :154
+    if ((rc = vec_op<P>(1, d_a, d_c, nullptr, N, false))) return rc;                        // ab -= c (:156-158)
     // divide_by_vanishing_poly_on_coset: multiply by (g^N - 1)^-1  (domain.rs:245-256, :229-231)
     Fp gen = fp_from_abi<P>(reinterpret_cast<const uint32_t*>(FieldConsts<P>::gen_m()));
     Fp gn = gen;
@@ -175,8 +179,8 @@ template <class P> int witness_map_t(int fidx, void* d_a, void* d_b, void* d_c, 
     Fp vinv = host_fp_inv<P>(fp_sub<P>(gn, fp_one<P>()));
     uint64_t vinv_abi[12];
     fp_to_abi<P>(reinterpret_cast<uint32_t*>(vinv_abi), vinv);
-    if ((rc = vec_op<P>(2, d_a, nullptr, vinv_abi, N))) return rc;
-    if ((rc = fft_run<P>(fidx, d_a, log_n, GH_FFT_INVERSE | GH_FFT_COSET))) return rc;   // :161
+    if ((rc = vec_op<P>(2, d_a, nullptr, vinv_abi, N, false))) return rc;
+    if ((rc = fft_run<P>(fidx, d_a, log_n, GH_FFT_INVERSE | GH_FFT_COSET, false))) return rc;   // :161
     // h (:124-132, :163-166)
     Fp f1 = fp_from_abi<P>(reinterpret_cast<const uint32_t*>(d1)), f2 = fp_from_abi<P>(reinterpret_cast<const uint32_t*>(d2));
     Fp f3 = fp_from_abi<P>(reinterpret_cast<const uint32_t*>(d3));

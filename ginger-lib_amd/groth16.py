@@ -11,7 +11,118 @@ tests and for the replay of BASELINE config 5 from exported buffers (SURVEY.md s
   * five MSMs per proof instead of nine: four on G1 as ONE pipelined batch (gh_msm_resident_dev_batch),
     one on G2.
 """
+import struct
+
 import numpy as np
+
+# base-field bytes of one coordinate coefficient / degree of the G2 coordinate field / bytes of the target-field element
+# vk.alpha_g1_beta_g2 (Fq4 resp. Fq6: carried as opaque bytes -- pairings are out of scope, the prover never reads it)
+_FQ_BYTES = 96
+_G2_DEG = {"mnt4753": 2, "mnt6753": 3}
+_FQK_BYTES = {"mnt4753": 4 * 96, "mnt6753": 6 * 96}
+_MODULUS = {   # r = scalar field of the pairing = base field of the other curve (SURVEY F5)
+    "mnt4753": 0x1c4c62d92c41110229022eee2cdadb7f997505b8fafed5eb7e8f96c97d87307fdb925e8a0ed8d99d124d9a15af79db26c5c28c859a99b3eebca9429212636b9dff97634993aa4d6c381bc3f0057974ea099170fa13a4fd90776e240000001,
+    "mnt6753": 0x1c4c62d92c41110229022eee2cdadb7f997505b8fafed5eb7e8f96c97d87307fdb925e8a0ed8d99d124d9a15af79db117e776f218059db80f0da5cb537e38685acce9767254a4638810719ac425f0e39d54522cdd119f5e9063de245e8001,
+}
+
+
+def parse_parameters(pairing, blob):
+    """Parameters::write stream (proof-systems/src/groth16/mod.rs:188-208; VerifyingKey::write :104-114) -> dict of byte
+    strings: single points as GroupAffine::write records (x || y || infinity byte, canonical little-endian coefficients:
+    short_weierstrass_projective.rs:185-192), queries as their records back to back.  Lengths are big-endian u32."""
+    g1 = 2 * _FQ_BYTES + 1
+    g2 = 2 * _FQ_BYTES * _G2_DEG[pairing] + 1
+    pos = 0
+
+    def take(nbytes):
+        nonlocal pos
+        if pos + nbytes > len(blob):
+            raise ValueError("Parameters stream is truncated")
+        out = bytes(blob[pos:pos + nbytes])
+        pos += nbytes
+        return out
+
+    def vec(rec):
+        (count,) = struct.unpack(">I", take(4))
+        return take(count * rec)
+
+    pk = {"vk_alpha_g1_beta_g2": take(_FQK_BYTES[pairing]), "vk_gamma_g2": take(g2), "vk_delta_g2": take(g2)}
+    pk["vk_gamma_abc_g1"] = vec(g1)
+    for name, rec in (("alpha_g1", g1), ("beta_g1", g1), ("beta_g2", g2), ("delta_g1", g1), ("delta_g2", g2)):
+        pk[name] = take(rec)
+    for name, rec in (("a_query", g1), ("b_g1_query", g1), ("b_g2_query", g2), ("h_query", g1), ("l_query", g1)):
+        pk[name] = vec(rec)
+    if pos != len(blob):
+        raise ValueError("trailing bytes after the Parameters stream")
+    return pk
+
+
+def benchmark_circuit_rows(pairing, num_constraints):
+    """The `Benchmark` circuit of proof-systems/src/groth16/examples/snark-scalability/constraints.rs:20-92 evaluated at its
+    own witness: returns (num_inputs, full assignment, A, B, C) as Python integer lists -- the vectors `a`, `b`, `c`
+    R1CStoQAP::witness_map forms from the constraint rows (r1cs_to_qap.rs:105-119, :141-151; before padding to the domain).
+    Host scalar code, as in the reference (synthesis is not on the device path).  The circuit has two public inputs
+    a = b = 1, alternating a + b = c / a * b = c steps and one closing constraint (sum of the recorded assignments)^2;
+    the recording pushes (a, a) twice and never b -- reproduced as written (:31-36)."""
+    r = _MODULUS[pairing]
+    num_inputs = 3                                           # one, a, b
+    inputs = [1, 1, 1]
+    aux = []
+    A, B, C = [], [], []
+    recorded = [(1, ("in", 1)), (1, ("in", 1))]              # (a_val, a_var) twice
+    a_val, a_var, b_val, b_var = 1, ("in", 1), 1, ("in", 2)
+    for i in range(num_constraints - 1):
+        if i % 2 != 0:
+            c_val = a_val * b_val % r
+            A.append(a_val); B.append(b_val); C.append(c_val)
+        else:
+            c_val = (a_val + b_val) % r
+            A.append(c_val); B.append(1); C.append(c_val)    # (a + b) * one = c
+        c_var = ("aux", len(aux))
+        aux.append(c_val)
+        recorded.append((c_val, c_var))
+        a_val, a_var, b_val, b_var = b_val, b_var, c_val, c_var
+    total = sum(v for v, _ in recorded) % r
+    c_val = total * total % r
+    aux.append(c_val)
+    A.append(total); B.append(total); C.append(c_val)
+    return num_inputs, inputs + aux, A, B, C
+
+
+def _mont_rows(vals, modulus):
+    """Python integers -> n x 12 u64 Montgomery rows (x * 2^768 mod p), the in-memory form of Fp768 (fp_768.rs:24-30)"""
+    R = (1 << 768) % modulus
+    out = np.zeros((len(vals), 12), dtype=np.uint64)
+    mask = (1 << 64) - 1
+    for i, v in enumerate(vals):
+        x = v * R % modulus
+        for k in range(12):
+            out[i, k] = (x >> (64 * k)) & mask
+    return out
+
+
+def _canon_rows(vals):
+    out = np.zeros((len(vals), 12), dtype=np.uint64)
+    mask = (1 << 64) - 1
+    for i, v in enumerate(vals):
+        for k in range(12):
+            out[i, k] = (v >> (64 * k)) & mask
+    return out
+
+
+def affine_to_wire(pairing, group, xy, is_infinity):
+    """GroupAffine::write of an affine result (Montgomery x || y limbs from gh_proj_to_affine): canonical little-endian
+    coefficients + infinity byte; zero() is written as (0, 1, true) (swp.rs:130-132)."""
+    p = _MODULUS["mnt6753" if pairing == "mnt4753" else "mnt4753"]      # base field of the pairing's curves
+    deg = 1 if group == "g1" else _G2_DEG[pairing]
+    rinv = pow(1 << 768, -1, p)
+    v = [int(x) for x in np.asarray(xy, dtype=np.uint64).ravel()]
+    out = bytearray()
+    for c in range(2 * deg):
+        m = sum(v[12 * c + k] << (64 * k) for k in range(12))
+        out += (m * rinv % p).to_bytes(_FQ_BYTES, "little")
+    out.append(1 if is_infinity else 0)
+    return bytes(out)
 
 
 class ResidentProvingKey:
@@ -47,9 +158,82 @@ class ResidentProvingKey:
                     pass                      # no memory for the table / a point of 2-power order: per-window path
             self.keys[name] = rb
 
+    @classmethod
+    def from_parameters(cls, gl, pairing, blob, num_inputs, precompute=True):
+        """The same resident key straight from a Parameters::write stream (a proving-key file): every query goes to the
+        device in its serialised form (gh_bases_upload_wire: canonical coefficients, infinity flags honoured -- keys made by
+        the reference generator contain GroupAffine::zero() entries wherever a variable does not occur in A or B)."""
+        self = cls.__new__(cls)
+        self.gl, self.num_inputs = gl, int(num_inputs)
+        self.g1, self.g2 = pairing + "_g1", pairing + "_g2"
+        pk = parse_parameters(pairing, blob)
+        self.pk = pk
+        self.pairing = pairing
+        r1, r2 = 2 * _FQ_BYTES + 1, 2 * _FQ_BYTES * _G2_DEG[pairing] + 1
+        ext = lambda q, c, d, rec: pk[q][rec:] + pk[q][:rec] + pk[c] + pk[d]          # q[1..] || q[0] || c || d
+        vectors = {"a": (self.g1, ext("a_query", "alpha_g1", "delta_g1", r1)),
+                   "b1": (self.g1, ext("b_g1_query", "beta_g1", "delta_g1", r1)),
+                   "b2": (self.g2, ext("b_g2_query", "beta_g2", "delta_g2", r2)),
+                   "h": (self.g1, pk["h_query"]), "l": (self.g1, pk["l_query"])}
+        self.keys = {}
+        for name, (curve, data) in vectors.items():
+            rb = gl.ResidentBases.from_wire(curve, data)
+            if precompute and rb.n:
+                try:
+                    rb.precompute(0)
+                except gl.GingerHipError:
+                    pass
+            self.keys[name] = rb
+        # delta_g1 as Montgomery limbs for the host-side r * s * delta term: through the device converter (one point)
+        one = gl.ResidentBases.from_wire(self.g1, pk["delta_g1"])
+        self.pk_delta_g1 = one.download(0, 1)[0]
+        one.free()
+        return self
+
     def free(self):
         for rb in self.keys.values():
             rb.free()
+
+    def create_proof(self, circuit_rows, d1, d2, d3, r, s):
+        """create_proof (prover.rs:201-345) for evaluated constraint rows: circuit_rows = (num_inputs, assignment, A, B, C) as
+        Python integers (benchmark_circuit_rows); d1, d2, d3, r, s integers.  Returns Proof::write bytes (mod.rs:35-42)."""
+        gl = self.gl
+        pairing = self.pairing
+        modulus = _MODULUS[pairing]
+        num_inputs, assignment, A, B, C = circuit_rows
+        assert num_inputs == self.num_inputs
+        n_con = len(A)
+        size = 1
+        while size < n_con + (num_inputs - 1) + 1:               # EvaluationDomain::new(num_constraints + num_inputs) (r1cs_to_qap.rs:100)
+            size <<= 1
+        log_n = size.bit_length() - 1
+        field = "mnt4753_fr" if pairing == "mnt4753" else "mnt6753_fr"
+        a = np.zeros((size, 12), dtype=np.uint64)
+        b = np.zeros((size, 12), dtype=np.uint64)
+        c = np.zeros((size, 12), dtype=np.uint64)
+        a[:n_con] = _mont_rows(A, modulus)
+        b[:n_con] = _mont_rows(B, modulus)
+        c[:n_con] = _mont_rows(C, modulus)
+        a[n_con:n_con + num_inputs] = _mont_rows([1] + list(assignment[1:num_inputs]), modulus)     # :116-118
+        dd = _mont_rows([d1, d2, d3], modulus)
+        lib = gl.load_library()
+        bufs = [gl.DeviceBuffer(size * 96 + 96) for _ in range(4)]
+        try:
+            for buf, arr in zip(bufs, (a, b, c)):
+                buf.upload(arr)
+            gl._check(lib.gh_witness_map_dev(gl.FIELDS[field], bufs[0].ptr, bufs[1].ptr, bufs[2].ptr, log_n, gl._ptr(dd[0]), gl._ptr(dd[1]),
+                                             gl._ptr(dd[2]), bufs[3].ptr))
+            one_plain = np.zeros(12, dtype=np.uint64)
+            one_plain[0] = 1
+            gl._check(lib.gh_vec_scale_dev(gl.FIELDS[field], bufs[3].ptr, gl._ptr(one_plain), size + 1))      # into_repr of h (:256-267)
+            scal = _canon_rows(assignment)
+            self.pk = dict(self.pk, delta_g1=self.pk_delta_g1)
+            A_, B_, C_ = self.create_proof_msms(scal[1:num_inputs], scal[num_inputs:], None, None, _canon_rows([r])[0], _canon_rows([s])[0],
+                                                h_dev=(bufs[3], self.keys["h"].n))
+        finally:
+            for buf in bufs:
+                buf.free()
+        return affine_to_wire(pairing, "g1", *A_) + affine_to_wire(pairing, "g2", *B_) + affine_to_wire(pairing, "g1", *C_)
 
     def create_proof_msms(self, input_assignment, aux_assignment, h_input_assignment, h_aux_assignment, r, s, h_dev=None):
         """All arguments are canonical 12-u64 scalars (rows).  Returns (A, B, C) as (xy, is_infinity) pairs:

@@ -150,11 +150,11 @@ int gh_fixed_base_free(gh_fixed_table_t table);
 /* Window size override for sweeps (0 = automatic).  Affects subsequent MSM calls. */
 int gh_msm_set_window(int c);
 int gh_msm_get_window(gh_curve_t curve, size_t n);
-/* Bucket sums in AFFINE coordinates (G1): pairwise rounds over the flat bucket-ordered list, the inversions
- * of a lane's whole batch shared by Montgomery's trick (5 M + 1 S + a share of one safegcd inversion per
- * addition instead of the 11 M of add_assign_mixed); P + P, P - P and sums through infinity handled in place.
- * Same results as the projective kernel.  mode: 0 never, 1 always, 2 (default) when the list is long enough
- * to fill the chip -- short MSMs stay projective, a round costs at least one inversion's latency.        */
+/* Bucket sums in AFFINE coordinates: pairwise rounds over the flat bucket-ordered list, the inversions of a
+ * lane's whole batch shared by Montgomery's trick (5 M + 1 S + a share of one safegcd inversion per addition
+ * instead of the 11 M of add_assign_mixed); P + P, P - P and sums through infinity handled in place.  Same
+ * results as the projective kernels.  mode: 0 never, 1 always, 2 (default) where measured faster: G2 MSMs
+ * long enough to fill the chip (G1 ties with its projective kernel and stays on it).                      */
 int gh_msm_set_affine(int mode);
 
 /* Time spent by the last MSM call in its phases, milliseconds (device phases by HIP events on the

@@ -277,3 +277,77 @@ def test_abi_two_threads(gpu):
         t.join()
     rb.free()
     assert not errors, errors
+
+
+# ------------------------------------------------------------------------------ config 5 end to end from reference-format bytes
+@pytest.mark.parametrize("pairing,num_constraints", [("mnt4753", 253), ("mnt6753", 125)])
+def test_cfg5_create_proof_from_parameters_bytes(gpu, pairing, num_constraints):
+    """create_proof end to end on reference-format bytes: a Parameters::write stream (groth16/mod.rs:188-208) made by the
+    first-principles generator (tests/groth16_ref.py) is parsed into five resident queries (infinity entries included), the
+    `Benchmark` circuit's rows are evaluated on the host, witness map and MSM stage run on the device, and the
+    Proof::write bytes (mod.rs:35-42) equal the oracle's literal replay of prover.rs:201-345 -- with and without shift tables."""
+    import groth16_ref as G
+    groth16 = importlib.import_module("ginger_lib_amd.groth16")
+    blob, info = G.generate_parameters(pairing, num_constraints, seed=7 + num_constraints)
+    pk = groth16.parse_parameters(pairing, blob)
+    C1 = pyref.CURVES[pairing + "_g1"]
+    n_b_inf = sum(1 for P in info["key"]["b_g1_query"] if P is None)
+    assert n_b_inf > 0                                           # the key does contain GroupAffine::zero() entries
+    assert len(pk["a_query"]) == 193 * len(info["key"]["a_query"]) and len(pk["h_query"]) == 193 * ((1 << info["log_n"]) - 1)
+    rng = pyref.Rng(99)
+    r_mod = C1.order
+    d1, d2, d3, r_, s_ = (rng.field_elem(r_mod) for _ in range(5))
+    rows = groth16.benchmark_circuit_rows(pairing, num_constraints)
+    assert rows[0] == info["num_inputs"] and rows[1] == info["assignment"]
+    exp = G.oracle_create_proof(pairing, info, d1, d2, d3, r_, s_)
+    for precompute in (False, True):
+        key = groth16.ResidentProvingKey.from_parameters(gpu, pairing, blob, info["num_inputs"], precompute=precompute)
+        try:
+            got = key.create_proof(rows, d1, d2, d3, r_, s_)
+        finally:
+            key.free()
+        assert got == exp, (pairing, precompute)
+    with pytest.raises(ValueError):
+        groth16.parse_parameters(pairing, blob[:-5])
+    gpu.dev_trim()
+
+
+def test_cfg5_benchmark_circuit_2p20_end_to_end(gpu):
+    """BASELINE config 5 at its own size: the `Benchmark` circuit with 2^20 - 3 constraints (domain 2^20), rows evaluated on the
+    host, device witness map + MSM stage over a synthetic resident key; proof bytes from the table path and from the per-window
+    path are identical.  (A reference-format key of this size would take the CPU generator hours; the byte path is checked at
+    small sizes above, the arithmetic at this size here.)"""
+    groth16 = importlib.import_module("ginger_lib_amd.groth16")
+    pairing = "mnt4753"
+    n_con = (1 << 20) - 3
+    rows = groth16.benchmark_circuit_rows(pairing, n_con)
+    ni, assignment = rows[0], rows[1]
+    assert ni == 3 and len(assignment) == 3 + n_con
+    C1, C2 = pyref.CURVES[pairing + "_g1"], pyref.CURVES[pairing + "_g2"]
+    nv = len(assignment)                                          # a_query has one entry per variable (incl. one)
+    N = 1 << 20
+
+    def chain(curve, n, seed):
+        Cc = pyref.CURVES[curve]
+        prng = pyref.Rng(seed)
+        xy, _ = S.bases_array(Cc, [Cc.mul(prng.next_u64() | 1, Cc.G), Cc.mul(prng.next_u64() | 1, Cc.G)])
+        rb = gpu.ResidentBases.chain(curve, xy[0], xy[1], n)
+        rows_ = rb.download(0, n)
+        rb.free()
+        return rows_
+    pk = {"a_query": chain(pairing + "_g1", nv, 1), "b_g1_query": chain(pairing + "_g1", nv, 2), "h_query": chain(pairing + "_g1", N - 1, 3),
+          "l_query": chain(pairing + "_g1", nv - ni, 4), "b_g2_query": chain(pairing + "_g2", nv, 5)}
+    pk.update({"alpha_g1": pk["h_query"][5], "beta_g1": pk["h_query"][6], "delta_g1": pk["h_query"][7],
+               "beta_g2": pk["b_g2_query"][5], "delta_g2": pk["b_g2_query"][7]})
+    rng = pyref.Rng(5)
+    d1, d2, d3, r_, s_ = (rng.field_elem(C1.order) for _ in range(5))
+    proofs = []
+    for precompute in (True, False):
+        key = groth16.ResidentProvingKey(gpu, pairing, pk, ni, precompute=precompute)
+        key.pairing, key.pk_delta_g1 = pairing, pk["delta_g1"]
+        try:
+            proofs.append(key.create_proof(rows, d1, d2, d3, r_, s_))
+        finally:
+            key.free()
+    assert proofs[0] == proofs[1] and len(proofs[0]) == 193 + 385 + 193
+    gpu.dev_trim()

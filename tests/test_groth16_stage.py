@@ -31,36 +31,40 @@ def _oracle_stage(pairing, pk, ni, inp, aux, h_inp, h_aux, r, s):
         C = pyref.CURVES[curve]
         return ec(curve, 3, S.proj_array(C, None), np.zeros(12, dtype=np.uint64))
 
-    def from_affine(curve, xy):                       # GroupProjective::from(affine): zero + affine (mixed add)
-        return ec(curve, 2, zero(curve), xy, 0)
+    def from_affine(curve, xy, inf=0):                # GroupProjective::from(affine): zero + affine (mixed add)
+        return ec(curve, 2, zero(curve), xy, int(inf))
+    first = lambda name: (pk[name][0], 0 if name + "_inf" not in pk else int(pk[name + "_inf"][0]))
 
     add = lambda curve, a, b: ec(curve, 0, a, b)
     mul = lambda curve, a, k: ec(curve, 3, a, k)
-    msm = lambda curve, bases, scal: S.oracle_msm(curve, bases, None, scal, 8)
+    # infinity flags of a query (keys made by the generator hold GroupAffine::zero() entries), sliced like the query
+    def msm(curve, bases, scal, inf=None):
+        return S.oracle_msm(curve, bases, inf, scal, 8)
+    q = lambda name, lo, hi=None: (pk[name][lo:hi], None if name + "_inf" not in pk else pk[name + "_inf"][lo:hi])
     neg = lambda curve, a: mul(curve, a, S.scalar_array([pyref.CURVES[curve].order - 1])[0])
 
     # prover.rs:273-284
-    a_inputs_acc = msm(g1, pk["a_query"][1:ni], inp)
-    a_aux_acc = msm(g1, pk["a_query"][ni:], aux)
+    a_inputs_acc = msm(g1, q("a_query", 1, ni)[0], inp, q("a_query", 1, ni)[1])
+    a_aux_acc = msm(g1, q("a_query", ni)[0], aux, q("a_query", ni)[1])
     g_a = mul(g1, from_affine(g1, pk["delta_g1"]), r)
-    for t in (from_affine(g1, pk["a_query"][0]), a_inputs_acc, a_aux_acc, from_affine(g1, pk["alpha_g1"])):
+    for t in (from_affine(g1, *first("a_query")), a_inputs_acc, a_aux_acc, from_affine(g1, pk["alpha_g1"])):
         g_a = add(g1, g_a, t)
     # :287-300
-    b_inputs_acc = msm(g1, pk["b_g1_query"][1:ni], inp)
-    b_aux_acc = msm(g1, pk["b_g1_query"][ni:], aux)
+    b_inputs_acc = msm(g1, q("b_g1_query", 1, ni)[0], inp, q("b_g1_query", 1, ni)[1])
+    b_aux_acc = msm(g1, q("b_g1_query", ni)[0], aux, q("b_g1_query", ni)[1])
     g1_b = mul(g1, from_affine(g1, pk["delta_g1"]), s)
-    for t in (from_affine(g1, pk["b_g1_query"][0]), b_inputs_acc, b_aux_acc, from_affine(g1, pk["beta_g1"])):
+    for t in (from_affine(g1, *first("b_g1_query")), b_inputs_acc, b_aux_acc, from_affine(g1, pk["beta_g1"])):
         g1_b = add(g1, g1_b, t)
     # :303-316
-    b2_inputs_acc = msm(g2, pk["b_g2_query"][1:ni], inp)
-    b2_aux_acc = msm(g2, pk["b_g2_query"][ni:], aux)
+    b2_inputs_acc = msm(g2, q("b_g2_query", 1, ni)[0], inp, q("b_g2_query", 1, ni)[1])
+    b2_aux_acc = msm(g2, q("b_g2_query", ni)[0], aux, q("b_g2_query", ni)[1])
     g2_b = mul(g2, from_affine(g2, pk["delta_g2"]), s)
-    for t in (from_affine(g2, pk["b_g2_query"][0]), b2_inputs_acc, b2_aux_acc, from_affine(g2, pk["beta_g2"])):
+    for t in (from_affine(g2, *first("b_g2_query")), b2_inputs_acc, b2_aux_acc, from_affine(g2, pk["beta_g2"])):
         g2_b = add(g2, g2_b, t)
     # :319-337
-    h_inputs_acc = msm(g1, pk["h_query"][0:ni], h_inp)
-    h_aux_acc = msm(g1, pk["h_query"][ni:], h_aux)
-    l_aux_acc = msm(g1, pk["l_query"], aux)
+    h_inputs_acc = msm(g1, q("h_query", 0, ni)[0], h_inp, q("h_query", 0, ni)[1])
+    h_aux_acc = msm(g1, q("h_query", ni)[0], h_aux, q("h_query", ni)[1])
+    l_aux_acc = msm(g1, q("l_query", 0)[0], aux, q("l_query", 0)[1])
     s_g_a = mul(g1, g_a, s)
     r_g1_b = mul(g1, g1_b, r)
     r_s_delta = mul(g1, mul(g1, from_affine(g1, pk["delta_g1"]), r), s)
