@@ -1,6 +1,6 @@
 #!/bin/bash
 # Reproduces the rocprofv3 evidence under profiles/ on an MI355X box (run from the repo root through gpurun):
-#   gpurun --timeout 900 -- 'bash tools/collect_profiles.sh gpurun_out/prof_rNN'
+#   gpurun --timeout 1100 -- 'bash tools/collect_profiles.sh gpurun_out/prof_rNN'
 # Kernel stats and counters are collected in separate runs (a --pmc run carries only --kernel-trace), the
 # program itself follows `--` (no env / bash -c hop: the profiler initialises the GPU before the program starts).
 set -o pipefail
@@ -8,9 +8,20 @@ OUT=${1:-gpurun_out/prof}
 R=$(pwd)
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$OUT/stats" -o run -- python3 "$R/bench.py" --no-cpu-baseline > "$R/$OUT/stats.log" 2>&1 || exit 1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$R/$OUT/fetch" -o run -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > "$R/$OUT/fetch.log" 2>&1 || exit 1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$R/$OUT/write" -o run -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > "$R/$OUT/write.log" 2>&1 || exit 1
+P="python3 $R/tools/acc_probe.py"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$OUT/stats" -o run -- python3 "$R/bench.py" --no-cpu-baseline --no-2p24 > "$R/$OUT/stats.log" 2>&1 || exit 1
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$R/$OUT/g1_$c" -o run -- $P mnt4753_g1 20 1 1 2 nocheck > "$R/$OUT/g1_$c.log" 2>&1 || exit 1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$R/$OUT/g2_$c" -o run -- $P mnt4753_g2 20 1 1 2 nocheck > "$R/$OUT/g2_$c.log" 2>&1 || exit 1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$R/$OUT/ntt_$c" -o run -- python3 "$R/tools/prof_run.py" ntt 24 3 > "$R/$OUT/ntt_$c.log" 2>&1 || exit 1
+done
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU --output-format csv \
-    -d "$R/$OUT/sq" -o run -- python3 "$R/tools/prof_run.py" msm 20 3 table > "$R/$OUT/sq.log" 2>&1 || exit 1
-ls "$R/$OUT"/*/
+    -d "$R/$OUT/sq_g1" -o run -- $P mnt4753_g1 20 1 1 2 nocheck > "$R/$OUT/sq_g1.log" 2>&1 || exit 1
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU --output-format csv \
+    -d "$R/$OUT/sq_g2" -o run -- $P mnt4753_g2 20 1 1 2 nocheck > "$R/$OUT/sq_g2.log" 2>&1 || exit 1
+cd "$R"
+python3 tools/make_traffic_json.py "$OUT/pmc_traffic.json" \
+  "mnt4753_g1_2p20:$OUT/g1_FETCH_SIZE/run_counter_collection.csv:$OUT/g1_WRITE_SIZE/run_counter_collection.csv:21:projective mixed additions" \
+  "mnt4753_g2_2p20:$OUT/g2_FETCH_SIZE/run_counter_collection.csv:$OUT/g2_WRITE_SIZE/run_counter_collection.csv:19:affine rounds (aff_kernels.h) + projective finish" \
+  "ntt_2p24:$OUT/ntt_FETCH_SIZE/run_counter_collection.csv:$OUT/ntt_WRITE_SIZE/run_counter_collection.csv:0:-" > "$OUT/pmc_traffic.log" 2>&1
+ls "$R/$OUT"
