@@ -12,7 +12,8 @@ curve, log_n = sys.argv[1], int(sys.argv[2])
 table = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 batch = int(sys.argv[4]) if len(sys.argv) > 4 else 6
 reps = int(sys.argv[5]) if len(sys.argv) > 5 else 3
-nocheck = len(sys.argv) > 6 and sys.argv[6] == "nocheck"       # profiling runs: the last MSM of the process is the measured one
+nocheck = len(sys.argv) > 6 and sys.argv[6] == "nocheck"
+c_table = int(os.environ.get("PROBE_C", "0"))                     # explicit window for the shift table (0 = the library's choice)       # profiling runs: the last MSM of the process is the measured one
 gl.init()
 C = pyref.CURVES[curve]
 n = 1 << log_n
@@ -25,7 +26,7 @@ ds = gl.DeviceBuffer(n * 96).upload(s)
 tag = " ".join("%s=%s" % (k, v) for k, v in sorted(os.environ.items()) if k.startswith("GH_"))
 if table:
     t0 = time.perf_counter()
-    c = rb.precompute(0)
+    c = rb.precompute(c_table)
     print("precompute c=%d %.2f s" % (c, time.perf_counter() - t0), flush=True)
 ref = None
 for r in range(reps):
