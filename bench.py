@@ -86,7 +86,17 @@ def main():
     backend = os.environ.get("GH_DIST_BACKEND", "rccl")
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("gloo")
+        # gloo prints its "[Gloo] Rank r is connected ..." lines on stdout; the contract is ONE JSON line there
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("gloo")
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
 
     import pyref
     from __graft_entry__ import _load_pkg
