@@ -34,6 +34,8 @@ ABI_SYMBOLS = [
     "gh_msm_set_window", "gh_msm_set_affine", "gh_msm_get_window", "gh_msm_last_timing", "gh_msm_batch_timing",
     "gh_domain_supported", "gh_fft", "gh_fft_dev", "gh_vec_mul_dev", "gh_vec_sub_dev", "gh_vec_scale_dev",
     "gh_vec_mul", "gh_vec_scale", "gh_fft_last_kernel_ms", "gh_witness_map", "gh_witness_map_dev",
+    "gh_sap_witness_map", "gh_sap_witness_map_dev", "gh_batch_inverse", "gh_batch_inverse_dev",
+    "gh_lagrange_coefficients", "gh_lagrange_coefficients_dev",
     "gh_dev_alloc", "gh_dev_free", "gh_dev_upload", "gh_dev_download", "gh_dev_sync", "gh_dev_trim",
     "gh_proj_add", "gh_proj_mul", "gh_proj_neg", "gh_proj_to_affine",
     "gh_fixed_base_window", "gh_fixed_base_table", "gh_fixed_base_msm", "gh_fixed_base_free",
@@ -102,6 +104,12 @@ def load_library():
     lib.gh_fft_last_kernel_ms.argtypes = [ctypes.POINTER(ctypes.c_float)]
     lib.gh_witness_map.argtypes = [ci, vp, vp, vp, u32, vp, vp, vp, vp]
     lib.gh_witness_map_dev.argtypes = [ci, vp, vp, vp, u32, vp, vp, vp, vp]
+    lib.gh_sap_witness_map.argtypes = [ci, vp, vp, u32, vp, vp, vp]
+    lib.gh_sap_witness_map_dev.argtypes = [ci, vp, vp, u32, vp, vp, vp]
+    lib.gh_batch_inverse.argtypes = [ci, vp, sz]
+    lib.gh_batch_inverse_dev.argtypes = [ci, vp, sz]
+    lib.gh_lagrange_coefficients.argtypes = [ci, u32, vp, vp]
+    lib.gh_lagrange_coefficients_dev.argtypes = [ci, u32, vp, vp]
     lib.gh_dev_alloc.argtypes = [ctypes.POINTER(vp), sz]
     lib.gh_dev_free.argtypes = [vp]
     lib.gh_dev_upload.argtypes = [vp, vp, sz]
@@ -447,6 +455,32 @@ def witness_map(field, a, b, c, d1, d2, d3):
     h = np.empty((n + 1) * 12, dtype=np.uint64)
     _check(load_library().gh_witness_map(FIELDS[field], _ptr(a), _ptr(b), _ptr(c), log_n, _ptr(d1), _ptr(d2), _ptr(d3), _ptr(h)))
     return h
+
+
+def sap_witness_map(field, a, c, d1, d2):
+    """Transform part of R1CStoSAP::witness_map (gm17/r1cs_to_sap.rs:194-240): a, c are the 2^k evaluations; returns h (2^k + 1)."""
+    a, c = _u64(a, 12), _u64(c, 12)
+    n = a.size // 12
+    assert n and (n & (n - 1)) == 0 and c.size == a.size
+    d1, d2 = _u64(d1, 12), _u64(d2, 12)
+    h = np.empty((n + 1) * 12, dtype=np.uint64)
+    _check(load_library().gh_sap_witness_map(FIELDS[field], _ptr(a), _ptr(c), n.bit_length() - 1, _ptr(d1), _ptr(d2), _ptr(h)))
+    return h
+
+
+def batch_inversion(field, a):
+    """algebra::fields::batch_inversion (fields/mod.rs:412-442) on Montgomery rows; zeros stay zero."""
+    a = _u64(a, 12).copy()
+    _check(load_library().gh_batch_inverse(FIELDS[field], _ptr(a), a.size // 12))
+    return a
+
+
+def evaluate_all_lagrange_coefficients(field, log_n, tau12):
+    """EvaluationDomain::evaluate_all_lagrange_coefficients (domain.rs:183-219) -> 2^log_n Montgomery rows"""
+    tau = _u64(tau12, 12)
+    out = np.empty((1 << log_n) * 12, dtype=np.uint64)
+    _check(load_library().gh_lagrange_coefficients(FIELDS[field], int(log_n), _ptr(tau), _ptr(out)))
+    return out.reshape(-1, 12)
 
 
 def vec_scale(field, a, scalar12):

@@ -430,6 +430,71 @@ int gh_witness_map(gh_field_t field, const uint64_t* a, const uint64_t* b, const
     return rc;
 }
 
+int gh_sap_witness_map_dev(gh_field_t field, void* d_a, void* d_c, uint32_t log_n, const uint64_t* d1, const uint64_t* d2, void* d_h) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!d_a || !d_c || !d_h || !d1 || !d2) { g_err = "null argument"; return GH_E_BAD_ARG; }
+    int rc = ensure_init();
+    if (rc) return rc;
+    return sap_witness_map(field, d_a, d_c, log_n, d1, d2, d_h);
+}
+
+int gh_sap_witness_map(gh_field_t field, const uint64_t* a, const uint64_t* c, uint32_t log_n, const uint64_t* d1, const uint64_t* d2, uint64_t* h) {
+    if (!a || !c || !h || !d1 || !d2) { std::lock_guard<std::mutex> lk(g_mu); g_err = "null argument"; return GH_E_BAD_ARG; }
+    if (log_n >= 31) { std::lock_guard<std::mutex> lk(g_mu); g_err = "domain too large"; return GH_E_UNSUPPORTED; }
+    const size_t bytes = ((size_t)1 << log_n) * 96;
+    void *da = nullptr, *dc = nullptr, *dh = nullptr;
+    int rc = gh_dev_alloc(&da, bytes);
+    if (!rc) rc = gh_dev_alloc(&dc, bytes);
+    if (!rc) rc = gh_dev_alloc(&dh, bytes + 96);
+    if (!rc) rc = gh_dev_upload(da, a, bytes);
+    if (!rc) rc = gh_dev_upload(dc, c, bytes);
+    if (!rc) rc = gh_sap_witness_map_dev(field, da, dc, log_n, d1, d2, dh);
+    if (!rc) rc = gh_dev_download(h, dh, bytes + 96);
+    gh_dev_free(da); gh_dev_free(dc); gh_dev_free(dh);
+    return rc;
+}
+
+int gh_batch_inverse_dev(gh_field_t field, void* d_a, size_t n) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (n && !d_a) { g_err = "null argument"; return GH_E_BAD_ARG; }
+    int rc = ensure_init();
+    if (rc) return rc;
+    return batch_inverse(field, d_a, n);
+}
+
+int gh_batch_inverse(gh_field_t field, uint64_t* a, size_t n) {
+    if (n == 0) return GH_OK;
+    if (!a) { std::lock_guard<std::mutex> lk(g_mu); g_err = "null argument"; return GH_E_BAD_ARG; }
+    void* da = nullptr;
+    int rc = gh_dev_alloc(&da, n * 96);
+    if (!rc) rc = gh_dev_upload(da, a, n * 96);
+    if (!rc) rc = gh_batch_inverse_dev(field, da, n);
+    if (!rc) rc = gh_dev_download(a, da, n * 96);
+    gh_dev_free(da);
+    return rc;
+}
+
+int gh_lagrange_coefficients_dev(gh_field_t field, uint32_t log_n, const uint64_t* tau12, void* d_out) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!tau12 || !d_out) { g_err = "null argument"; return GH_E_BAD_ARG; }
+    if (log_n >= 31) { g_err = "domain too large"; return GH_E_UNSUPPORTED; }
+    int rc = ensure_init();
+    if (rc) return rc;
+    return lagrange_coefficients(field, log_n, tau12, d_out);
+}
+
+int gh_lagrange_coefficients(gh_field_t field, uint32_t log_n, const uint64_t* tau12, uint64_t* out) {
+    if (!tau12 || !out) { std::lock_guard<std::mutex> lk(g_mu); g_err = "null argument"; return GH_E_BAD_ARG; }
+    if (log_n >= 31) { std::lock_guard<std::mutex> lk(g_mu); g_err = "domain too large"; return GH_E_UNSUPPORTED; }
+    const size_t bytes = ((size_t)1 << log_n) * 96;
+    void* d = nullptr;
+    int rc = gh_dev_alloc(&d, bytes);
+    if (!rc) rc = gh_lagrange_coefficients_dev(field, log_n, tau12, d);
+    if (!rc) rc = gh_dev_download(out, d, bytes);
+    gh_dev_free(d);
+    return rc;
+}
+
 int gh_fft_last_kernel_ms(float* ms) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (ms) *ms = g.last_fft_ms;

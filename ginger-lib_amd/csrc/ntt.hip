@@ -196,6 +196,112 @@ template <class P> int witness_map_t(int fidx, void* d_a, void* d_b, void* d_c, 
     return GH_OK;
 }
 
+// R1CStoSAP::witness_map, transform part (proof-systems/src/gm17/r1cs_to_sap.rs:194-240): d_a, d_c hold the 2^log_n
+// evaluations built by the caller (:158-192, :207-230); both are overwritten; d_h receives 2^log_n + 1 coefficients.
+template <class P> int sap_witness_map_t(int fidx, void* d_a, void* d_c, uint32_t log_n, const uint64_t* d1, const uint64_t* d2, void* d_h) {
+    const size_t N = (size_t)1 << log_n;
+    int rc;
+    if ((rc = fft_run<P>(fidx, d_a, log_n, GH_FFT_INVERSE, false))) return rc;                       // :191
+    // h = 2 d1 * a  (coefficients) (:193-195)
+    HIPCHK(hipMemcpyAsync(d_h, d_a, N * 96, hipMemcpyDeviceToDevice, g.stream));
+    Fp f1 = fp_from_abi<P>(reinterpret_cast<const uint32_t*>(d1)), f2 = fp_from_abi<P>(reinterpret_cast<const uint32_t*>(d2));
+    uint64_t d1_double[12];
+    fp_to_abi<P>(reinterpret_cast<uint32_t*>(d1_double), fp_dbl<P>(f1));
+    if ((rc = vec_op<P>(2, d_h, nullptr, d1_double, N, false))) return rc;
+    if ((rc = fft_run<P>(fidx, d_a, log_n, GH_FFT_COSET, false))) return rc;                         // :201
+    if ((rc = vec_op<P>(0, d_a, d_a, nullptr, N, false))) return rc;                                 // aa = a .* a (:203)
+    if ((rc = fft_run<P>(fidx, d_c, log_n, GH_FFT_INVERSE, false))) return rc;                       // :232
+    if ((rc = fft_run<P>(fidx, d_c, log_n, GH_FFT_COSET, false))) return rc;                         // :233
+    if ((rc = vec_op<P>(1, d_a, d_c, nullptr, N, false))) return rc;                                 // aa -= c (:235)
+    Fp gen = fp_from_abi<P>(reinterpret_cast<const uint32_t*>(FieldConsts<P>::gen_m()));
+    Fp gn = gen;
+    for (uint32_t i = 0; i < log_n; i++) gn = fp_sqr<P>(gn);
+    Fp vinv = host_fp_inv<P>(fp_sub<P>(gn, fp_one<P>()));
+    uint64_t vinv_abi[12];
+    fp_to_abi<P>(reinterpret_cast<uint32_t*>(vinv_abi), vinv);
+    if ((rc = vec_op<P>(2, d_a, nullptr, vinv_abi, N, false))) return rc;                            // :237
+    if ((rc = fft_run<P>(fidx, d_a, log_n, GH_FFT_INVERSE | GH_FFT_COSET, false))) return rc;        // :238
+    Fp d1d1 = fp_sqr<P>(f1);
+    Fp h0 = fp_neg<P>(fp_add<P>(f2, d1d1));                                                          // :196-198
+    uint32_t w0[24], w1[24];
+    fp_to_abi<P>(w0, h0);
+    fp_to_abi<P>(w1, d1d1);
+    hipLaunchKernelGGL((sap_finish_kernel<P>), dim3((unsigned)((N + 1 + 255) / 256)), dim3(256), 0, g.stream,
+                       (const uint32_t*)d_a, (uint32_t*)d_h, N, fp_unpack(w0), fp_unpack(w1));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(g.stream));
+    return GH_OK;
+}
+
+template <class P> int batch_inverse_t(void* d_a, size_t n) {
+    if (n == 0) return GH_OK;
+    Fp* tmp;
+    int rc = pool_get("inv_tmp", n * sizeof(Fp), (void**)&tmp);
+    if (rc) return rc;
+    const size_t threads = (n + INV_RUN - 1) / INV_RUN;
+    hipLaunchKernelGGL((batch_inverse_kernel<P>), dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, g.stream, (uint32_t*)d_a, tmp, n);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(g.stream));
+    return GH_OK;
+}
+
+template <class P> int lagrange_t(int fidx, uint32_t log_n, const uint64_t* tau12, void* d_out) {
+    if ((int)log_n >= FieldConsts<P>::two_adicity) { g_err = "domain exceeds the field's 2-adicity"; return GH_E_UNSUPPORTED; }
+    const size_t N = (size_t)1 << log_n;
+    const Fp tau = fp_from_abi<P>(reinterpret_cast<const uint32_t*>(tau12));
+    Fp t_size = tau;
+    for (uint32_t i = 0; i < log_n; i++) t_size = fp_sqr<P>(t_size);
+    const dim3 grid((unsigned)((N + 255) / 256)), blk(256);
+    Fp one_tab = fp_one<P>();
+    const Fp* tw = nullptr;
+    Fp* tw1 = nullptr;
+    if (log_n == 0) {                      // size-1 domain: w^0 = 1, no table
+        HIPCHK(hipMalloc((void**)&tw1, sizeof(Fp)));
+        HIPCHK(hipMemcpy(tw1, &one_tab, sizeof(Fp), hipMemcpyHostToDevice));
+        tw = tw1;
+    } else {
+        Domain* d;
+        int rc = get_domain<P>(fidx, (int)log_n, false, false, &d);
+        if (rc) return rc;
+        tw = d->tw;
+    }
+    int rc = GH_OK;
+    if (fp_eq(t_size, fp_one<P>())) {
+        hipLaunchKernelGGL((lagrange_kernel<P, 0>), grid, blk, 0, g.stream, (uint32_t*)d_out, tw, N, tau, fp_zero());
+    } else {
+        Fp n_int = fp_one<P>();
+        for (uint32_t i = 0; i < log_n; i++) n_int = fp_dbl<P>(n_int);
+        const Fp l0 = fp_mul<P>(fp_sub<P>(t_size, fp_one<P>()), host_fp_inv<P>(n_int));
+        hipLaunchKernelGGL((lagrange_kernel<P, 1>), grid, blk, 0, g.stream, (uint32_t*)d_out, tw, N, tau, l0);
+        rc = batch_inverse_t<P>(d_out, N);
+        if (!rc) hipLaunchKernelGGL((lagrange_kernel<P, 2>), grid, blk, 0, g.stream, (uint32_t*)d_out, tw, N, tau, l0);
+    }
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(g.stream);
+    if (tw1) (void)hipFree(tw1);
+    if (!rc && e != hipSuccess) { g_err = std::string("lagrange coefficients: ") + hipGetErrorString(e); rc = GH_E_HIP; }
+    return rc;
+}
+
+int sap_witness_map(gh_field_t field, void* d_a, void* d_c, uint32_t log_n, const uint64_t* d1, const uint64_t* d2, void* d_h) {
+    if (field == GH_MNT4753_FR) return sap_witness_map_t<P6>(0, d_a, d_c, log_n, d1, d2, d_h);
+    if (field == GH_MNT6753_FR) return sap_witness_map_t<P4>(1, d_a, d_c, log_n, d1, d2, d_h);
+    g_err = "unknown field id";
+    return GH_E_BAD_ARG;
+}
+int batch_inverse(gh_field_t field, void* d_a, size_t n) {
+    if (field == GH_MNT4753_FR) return batch_inverse_t<P6>(d_a, n);
+    if (field == GH_MNT6753_FR) return batch_inverse_t<P4>(d_a, n);
+    g_err = "unknown field id";
+    return GH_E_BAD_ARG;
+}
+int lagrange_coefficients(gh_field_t field, uint32_t log_n, const uint64_t* tau12, void* d_out) {
+    if (field == GH_MNT4753_FR) return lagrange_t<P6>(0, log_n, tau12, d_out);
+    if (field == GH_MNT6753_FR) return lagrange_t<P4>(1, log_n, tau12, d_out);
+    g_err = "unknown field id";
+    return GH_E_BAD_ARG;
+}
+
 int witness_map(gh_field_t field, void* d_a, void* d_b, void* d_c, uint32_t log_n, const uint64_t* d1,
                 const uint64_t* d2, const uint64_t* d3, void* d_h) {
     if (field == GH_MNT4753_FR) return witness_map_t<P6>(0, d_a, d_b, d_c, log_n, d1, d2, d3, d_h);

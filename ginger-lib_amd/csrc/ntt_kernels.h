@@ -225,6 +225,67 @@ __global__ void __launch_bounds__(256) witness_finish_kernel(const uint32_t* ab,
     st_abi_raw(h + i * 24, v);
 }
 
+// last step of the GM17 / SAP witness map (proof-systems/src/gm17/r1cs_to_sap.rs:194-240): hbase holds 2 d1 * ifft(a),
+//   h[i] = hbase[i] + aa[i] (i < N - 1);  h[N-1] = hbase[N-1];  h[0] += h0_add (= -d2 - d1^2);  h[N] = d1^2
+template <class P>
+__global__ void __launch_bounds__(256) sap_finish_kernel(const uint32_t* aa, uint32_t* h, size_t N, Fp h0_add, Fp h_last) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > N) return;
+    Fp v;
+    if (i == N) v = h_last;
+    else {
+        v = ld_abi_raw(h + i * 24);
+        if (i < N - 1) v = fp_add<P>(v, ld_abi_raw(aa + i * 24));
+        if (i == 0) v = fp_add<P>(v, h0_add);
+    }
+    st_abi_raw(h + i * 24, v);
+}
+
+// batch_inversion (algebra/src/fields/mod.rs:412-442): a[i] <- a[i]^-1, zeros are left alone.  One thread per run of
+// INV_RUN elements: Montgomery's trick inside the run (running products parked in `tmp`), one safegcd inversion per thread.
+constexpr int INV_RUN = 32;
+template <class P>
+__global__ void __launch_bounds__(64) batch_inverse_kernel(uint32_t* a, Fp* tmp, size_t n) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t i0 = t * INV_RUN;
+    if (i0 >= n) return;
+    const int cnt = (int)(n - i0 < (size_t)INV_RUN ? n - i0 : (size_t)INV_RUN);
+    Fp run = fp_one<P>();
+    for (int j = 0; j < cnt; j++) {
+        const Fp x = fp_from_abi<P>(a + (i0 + j) * 24);
+        if (!fp_is_zero(x)) run = fp_mul<P>(run, x);
+        st_fp(tmp + i0 + j, run);                          // product of the non-zero elements up to and including j
+    }
+    Fp inv = fp_inv<P>(run);
+    for (int j = cnt - 1; j >= 0; j--) {
+        const Fp x = fp_from_abi<P>(a + (i0 + j) * 24);
+        if (fp_is_zero(x)) continue;
+        const Fp before = j > 0 ? ld_fp(tmp + i0 + j - 1) : fp_one<P>();
+        fp_to_abi<P>(a + (i0 + j) * 24, fp_mul<P>(inv, before));
+        inv = fp_mul<P>(inv, x);
+    }
+}
+
+// evaluate_all_lagrange_coefficients (algebra/src/fft/domain.rs:183-219), tau outside the domain:
+//   step 1: out[i] = tau - w^i            (then batch_inverse_kernel)
+//   step 2: out[i] = out[i] * l0 * w^i    with l0 = (tau^N - 1) / N
+// tau in the domain (tau^N = 1): out[i] = (w^i == tau) ? 1 : 0.   tw: w^i in internal form; tau, l0 internal.
+template <class P, int STEP>
+__global__ void __launch_bounds__(256) lagrange_kernel(uint32_t* out, const Fp* __restrict__ tw, size_t N, Fp tau, Fp l0) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const Fp w = ld_fp(tw + i);
+    if (STEP == 0) {            // indicator
+        if (fp_eq(w, tau)) fp_to_abi<P>(out + i * 24, fp_one<P>());
+        else st_abi_raw(out + i * 24, fp_zero());
+    } else if (STEP == 1) {
+        fp_to_abi<P>(out + i * 24, fp_sub<P>(tau, w));
+    } else {
+        const Fp x = fp_from_abi<P>(out + i * 24);
+        fp_to_abi<P>(out + i * 24, fp_mul<P>(x, fp_mul<P>(l0, w)));
+    }
+}
+
 // ABI Montgomery -> internal Montgomery for a vector of n elements (table seeds etc.)
 template <class P>
 __global__ void __launch_bounds__(256) abi_to_internal_kernel(const uint32_t* in, Fp* out, size_t n) {

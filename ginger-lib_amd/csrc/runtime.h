@@ -101,5 +101,8 @@ int fft_run(gh_field_t field, void* d_data, uint32_t log_n, uint32_t flags);
 int vec_op(gh_field_t field, int op, void* d_a, const void* d_b, const uint64_t* scalar12, size_t n);
 int witness_map(gh_field_t field, void* d_a, void* d_b, void* d_c, uint32_t log_n, const uint64_t* d1,
                 const uint64_t* d2, const uint64_t* d3, void* d_h);
+int sap_witness_map(gh_field_t field, void* d_a, void* d_c, uint32_t log_n, const uint64_t* d1, const uint64_t* d2, void* d_h);
+int batch_inverse(gh_field_t field, void* d_a, size_t n);
+int lagrange_coefficients(gh_field_t field, uint32_t log_n, const uint64_t* tau12, void* d_out);
 
 }  // namespace gh_rt

@@ -216,6 +216,24 @@ int gh_witness_map_dev(gh_field_t field, void* d_a, void* d_b, void* d_c, uint32
 int gh_witness_map(gh_field_t field, const uint64_t* a, const uint64_t* b, const uint64_t* c, uint32_t log_n,
                    const uint64_t* d1, const uint64_t* d2, const uint64_t* d3, uint64_t* h);
 
+/* GM17 / SAP witness map, device resident: the transform part of R1CStoSAP::witness_map
+ * (proof-systems/src/gm17/r1cs_to_sap.rs:194-240).  d_a, d_c hold the 2^log_n evaluations the caller built
+ * (:158-192 a, :207-230 c; host scalar code); both are overwritten; d_h receives 2^log_n + 1 coefficients:
+ *   a = ifft(a); h = 2 d1 a; h[0] -= d2 + d1^2; a = coset_fft(a); aa = a .* a; c = coset_fft(ifft(c));
+ *   aa = coset_ifft((aa - c) / Z); h[i] += aa[i] (i < N - 1); h[N] = d1^2                                   */
+int gh_sap_witness_map_dev(gh_field_t field, void* d_a, void* d_c, uint32_t log_n, const uint64_t* d1, const uint64_t* d2, void* d_h);
+int gh_sap_witness_map(gh_field_t field, const uint64_t* a, const uint64_t* c, uint32_t log_n, const uint64_t* d1,
+                       const uint64_t* d2, uint64_t* h);
+
+/* batch_inversion (algebra/src/fields/mod.rs:412-442): a[i] <- 1 / a[i] for n Montgomery elements, zeros are left alone. */
+int gh_batch_inverse_dev(gh_field_t field, void* d_a, size_t n);
+int gh_batch_inverse(gh_field_t field, uint64_t* a, size_t n);
+
+/* EvaluationDomain::evaluate_all_lagrange_coefficients (algebra/src/fft/domain.rs:183-219): out[i] = L_i(tau) for the
+ * domain of size 2^log_n; tau a Montgomery element; tau inside the domain gives the indicator vector (:189-199). */
+int gh_lagrange_coefficients_dev(gh_field_t field, uint32_t log_n, const uint64_t* tau12, void* d_out);
+int gh_lagrange_coefficients(gh_field_t field, uint32_t log_n, const uint64_t* tau12, uint64_t* out);
+
 /* Duration of the kernels of the last gh_fft / gh_fft_dev call (HIP events), milliseconds. */
 int gh_fft_last_kernel_ms(float* ms);
 

@@ -672,4 +672,83 @@ void witness_map(std::vector<Fp<P>>& a, std::vector<Fp<P>>& b, std::vector<Fp<P>
     for (size_t i = 0; i + 1 < n; i++) h[i].add_assign(ab[i]);                    // :163-166
 }
 
+// ---- algebra/src/fields/mod.rs:412-442  batch_inversion (Montgomery's trick; zero elements are skipped)
+template <class P> void batch_inversion(Fp<P>* v, size_t n) {
+    typedef Fp<P> F;
+    std::vector<F> prod;
+    prod.reserve(n);
+    F tmp = F::one();
+    for (size_t i = 0; i < n; i++) if (!v[i].is_zero()) { tmp.mul_assign(v[i]); prod.push_back(tmp); }       // :418-423
+    F ti; tmp.inverse(ti); tmp = ti;                                                                        // :426
+    size_t k = prod.size();
+    for (size_t i = n; i-- > 0;) {                                                                          // :429-441, backwards
+        if (v[i].is_zero()) continue;
+        k--;
+        const F s = k > 0 ? prod[k - 1] : F::one();
+        const F newtmp = tmp.mul(v[i]);
+        v[i] = tmp.mul(s);
+        tmp = newtmp;
+    }
+}
+
+// ---- algebra/src/fft/domain.rs:183-219  evaluate_all_lagrange_coefficients
+template <class P> std::vector<Fp<P>> evaluate_all_lagrange_coefficients(const Domain<P>& d, const Fp<P>& tau) {
+    typedef Fp<P> F;
+    const size_t size = d.size;
+    uint64_t e = size;
+    const F t_size = tau.pow(&e, 1);                                                                        // :186
+    const F one = F::one();
+    std::vector<F> u(size, F::zero());
+    if (t_size == one) {                                                                                    // :188-199
+        F omega_i = one;
+        for (size_t i = 0; i < size; i++) {
+            if (omega_i == tau) { u[i] = one; break; }
+            omega_i.mul_assign(d.group_gen);
+        }
+        return u;
+    }
+    F l = t_size.sub(one).mul(d.size_inv);                                                                  // :203
+    F r = one;
+    std::vector<F> ls(size, F::zero());
+    for (size_t i = 0; i < size; i++) {                                                                     // :207-212
+        u[i] = tau.sub(r);
+        ls[i] = l;
+        l.mul_assign(d.group_gen);
+        r.mul_assign(d.group_gen);
+    }
+    batch_inversion<P>(u.data(), size);                                                                     // :214
+    for (size_t i = 0; i < size; i++) u[i] = ls[i].mul(u[i]);                                               // :215-217
+    return u;
+}
+
+// ---- proof-systems/src/gm17/r1cs_to_sap.rs:191-240  witness_map, from the evaluated rows on
+// (a, c: domain-size vectors as built at :158-190 and :207-230).
+template <class P>
+void sap_witness_map(std::vector<Fp<P>>& a, std::vector<Fp<P>>& c, uint32_t log_n, const Fp<P>& d1, const Fp<P>& d2,
+                     std::vector<Fp<P>>& h, int threads) {
+    typedef Fp<P> F;
+    Domain<P> d;
+    Domain<P>::create((size_t)1 << log_n, d);
+    const size_t n = d.size;
+    domain_transform<P>(d, a.data(), n, true, false, threads);                    // ifft_in_place(a)  :191
+    const F d1_double = d1.dbl();                                                 // :193
+    h.assign(n, d1_double);                                                       // :194
+    for (size_t i = 0; i < n; i++) h[i].mul_assign(a[i]);                         // :195
+    h[0].sub_assign(d2);                                                          // :196
+    const F d1d1 = d1.square();                                                   // :197
+    h[0].sub_assign(d1d1);                                                        // :198
+    h.push_back(d1d1);                                                            // :199
+    domain_transform<P>(d, a.data(), n, false, true, threads);                    // coset_fft(a) :201
+    std::vector<F> aa(a);
+    for (size_t i = 0; i < n; i++) aa[i].mul_assign(a[i]);                        // :203
+    domain_transform<P>(d, c.data(), n, true, false, threads);                    // :232
+    domain_transform<P>(d, c.data(), n, false, true, threads);                    // :233
+    for (size_t i = 0; i < n; i++) aa[i].sub_assign(c[i]);                        // :235
+    uint64_t e = n;
+    F vi; F::multiplicative_generator().pow(&e, 1).sub(F::one()).inverse(vi);     // divide_by_vanishing_poly_on_coset :237
+    for (size_t i = 0; i < n; i++) aa[i].mul_assign(vi);
+    domain_transform<P>(d, aa.data(), n, true, true, threads);                    // coset_ifft :238
+    for (size_t i = 0; i + 1 < n; i++) h[i].add_assign(aa[i]);                    // :240-243
+}
+
 }  // namespace oracle

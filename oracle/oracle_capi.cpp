@@ -233,4 +233,45 @@ int oracle_witness_map(int field, const uint64_t* a, const uint64_t* b, const ui
     }
     return 0;
 }
+// batch_inversion (fields/mod.rs:412-442) in place on n Montgomery elements
+int oracle_batch_inversion(int field, uint64_t* a, size_t n) {
+    if (field == 0) batch_inversion<P6>(reinterpret_cast<Fp<P6>*>(a), n);
+    else batch_inversion<P4>(reinterpret_cast<Fp<P4>*>(a), n);
+    return 0;
+}
+// evaluate_all_lagrange_coefficients (domain.rs:183-219): out receives 2^log_n elements
+int oracle_lagrange(int field, uint32_t log_n, const uint64_t* tau, uint64_t* out) {
+    const size_t n = (size_t)1 << log_n;
+    if (field == 0) {
+        Domain<P6> d; if (!Domain<P6>::create(n, d)) return -2;
+        Fp<P6> t; memcpy(t.v.l, tau, 96);
+        auto u = evaluate_all_lagrange_coefficients<P6>(d, t);
+        memcpy(out, u.data(), n * 96);
+    } else {
+        Domain<P4> d; if (!Domain<P4>::create(n, d)) return -2;
+        Fp<P4> t; memcpy(t.v.l, tau, 96);
+        auto u = evaluate_all_lagrange_coefficients<P4>(d, t);
+        memcpy(out, u.data(), n * 96);
+    }
+    return 0;
+}
+// R1CStoSAP::witness_map (gm17/r1cs_to_sap.rs:191-240) from evaluated rows; h_out receives 2^log_n + 1 elements
+int oracle_sap_witness_map(int field, const uint64_t* a, const uint64_t* c, uint32_t log_n, const uint64_t* d1, const uint64_t* d2,
+                           uint64_t* h_out, int threads) {
+    const size_t n = (size_t)1 << log_n;
+    if (field == 0) {
+        std::vector<Fp<P6>> va(n), vc(n), h;
+        memcpy(va.data(), a, n * 96); memcpy(vc.data(), c, n * 96);
+        Fp<P6> f1, f2; memcpy(f1.v.l, d1, 96); memcpy(f2.v.l, d2, 96);
+        sap_witness_map<P6>(va, vc, log_n, f1, f2, h, threads);
+        memcpy(h_out, h.data(), (n + 1) * 96);
+    } else {
+        std::vector<Fp<P4>> va(n), vc(n), h;
+        memcpy(va.data(), a, n * 96); memcpy(vc.data(), c, n * 96);
+        Fp<P4> f1, f2; memcpy(f1.v.l, d1, 96); memcpy(f2.v.l, d2, 96);
+        sap_witness_map<P4>(va, vc, log_n, f1, f2, h, threads);
+        memcpy(h_out, h.data(), (n + 1) * 96);
+    }
+    return 0;
+}
 }

@@ -34,6 +34,10 @@ def oracle():
         lib.oracle_vec_mul.argtypes = [ci, vp, vp, sz]
         lib.oracle_vanishing_inv_on_coset.argtypes = [ci, u32, vp]
         lib.oracle_witness_map.argtypes = [ci, vp, vp, vp, u32, vp, vp, vp, vp, ci]
+        lib.oracle_batch_inversion.argtypes = [ci, vp, sz]
+        lib.oracle_lagrange.argtypes = [ci, u32, vp, vp]
+        lib.oracle_sap_witness_map.argtypes = [ci, vp, vp, u32, vp, vp, vp, ci]
+        lib.oracle_fixed_base_msm.argtypes = [ci, vp, sz, sz, vp, sz, vp, ci]
         _oracle = lib
     return _oracle
 
@@ -178,4 +182,28 @@ def oracle_witness_map(field, a, b, c, d1, d2, d3, threads=8):
     d1, d2, d3 = (np.ascontiguousarray(x, dtype=np.uint64) for x in (d1, d2, d3))
     rc = oracle().oracle_witness_map(FIELD_ID[field], ptr(a), ptr(b), ptr(c), log_n, ptr(d1), ptr(d2), ptr(d3), ptr(h), threads)
     assert rc == 0
+    return h
+
+
+def oracle_batch_inversion(field, a):
+    a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 12).copy()
+    assert oracle().oracle_batch_inversion(FIELD_ID[field], ptr(a), len(a)) == 0
+    return a
+
+
+def oracle_lagrange(field, log_n, tau12):
+    out = np.zeros((1 << log_n, 12), dtype=np.uint64)
+    tau = np.ascontiguousarray(tau12, dtype=np.uint64)
+    assert oracle().oracle_lagrange(FIELD_ID[field], log_n, ptr(tau), ptr(out)) == 0
+    return out
+
+
+def oracle_sap_witness_map(field, a, c, d1, d2, threads=8):
+    """restated R1CStoSAP::witness_map (gm17/r1cs_to_sap.rs:191-240) from evaluated rows -> h (N + 1 elements)"""
+    a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 12)
+    n = len(a)
+    c = np.ascontiguousarray(c, dtype=np.uint64)
+    h = np.zeros((n + 1, 12), dtype=np.uint64)
+    d1, d2 = (np.ascontiguousarray(x, dtype=np.uint64) for x in (d1, d2))
+    assert oracle().oracle_sap_witness_map(FIELD_ID[field], ptr(a), ptr(c), n.bit_length() - 1, ptr(d1), ptr(d2), ptr(h), threads) == 0
     return h

@@ -115,6 +115,39 @@ def test_witness_map_vs_oracle(gpu, field, log_n):
         assert (got == exp).all()
 
 
+@pytest.mark.parametrize("field,log_n", [("mnt4753_fr", 0), ("mnt4753_fr", 1), ("mnt4753_fr", 11), ("mnt4753_fr", 16), ("mnt6753_fr", 8)])
+def test_sap_witness_map_vs_oracle(gpu, field, log_n):
+    """R1CStoSAP::witness_map transform pipeline (gm17/r1cs_to_sap.rs:191-240), arbitrary rows and d1 d2"""
+    F = S.FIELD_OF[field]
+    n = 1 << log_n
+    a, c = (S.random_scalars_np(n, seed=s0 + log_n, below=F.p) for s0 in (400, 500))
+    for zero_d in (True, False):
+        d = np.zeros((2, 12), dtype=np.uint64) if zero_d else S.random_scalars_np(2, seed=19, below=F.p)
+        got = gpu.sap_witness_map(field, a, c, d[0], d[1]).reshape(n + 1, 12)
+        exp = S.oracle_sap_witness_map(field, a, c, d[0], d[1], 16)
+        assert (got == exp).all()
+
+
+@pytest.mark.parametrize("field", ["mnt4753_fr", "mnt6753_fr"])
+def test_batch_inversion_and_lagrange_vs_oracle(gpu, field):
+    """batch_inversion (fields/mod.rs:412-442: zeros skipped; sizes around the per-thread run of 32) and
+    evaluate_all_lagrange_coefficients (domain.rs:183-219: tau outside the domain, tau = a domain element, sizes 1 .. 2^12)"""
+    F = S.FIELD_OF[field]
+    for n in (1, 2, 31, 32, 33, 1000, 5000):
+        a = S.random_scalars_np(n, seed=600 + n, below=F.p)
+        a[::7] = 0
+        assert (gpu.batch_inversion(field, a).reshape(n, 12) == S.oracle_batch_inversion(field, a)).all(), n
+    a = S.fe_array(F, [1, F.p - 1, 2])
+    assert S.fe_list(F, gpu.batch_inversion(field, a).reshape(3, 12)) == [1, F.p - 1, pow(2, -1, F.p)]
+    tau = S.random_scalars_np(1, seed=77, below=F.p)[0]
+    for log_n in (0, 1, 5, 12):
+        assert (gpu.evaluate_all_lagrange_coefficients(field, log_n, tau) == S.oracle_lagrange(field, log_n, tau)).all(), log_n
+    w = pyref.domain_params(F, 6)
+    inside = S.fe_array(F, [pow(w, 37, F.p)])[0]
+    got = gpu.evaluate_all_lagrange_coefficients(field, 6, inside)
+    assert (got == S.oracle_lagrange(field, 6, inside)).all() and S.fe_list(F, got) == [1 if i == 37 else 0 for i in range(64)]
+
+
 # ------------------------------------------------------------------------------ MSM
 def load_msm_case(name):
     case = MSM_G[name]

@@ -134,3 +134,39 @@ def test_oracle_witness_map_first_principles():
     d1, d2, d3 = (rng.field_elem(p) for _ in range(3))
     h = S.fe_list(F, S.oracle_witness_map("mnt4753_fr", A, B, C, S.fe_array(F, [d1]), S.fe_array(F, [d2]), S.fe_array(F, [d3])))
     assert h == [(q[0] - d3 - d1 * d2) % p] + q[1:] + [0, (d1 * d2) % p]
+
+
+def test_batch_inversion_lagrange_and_sap_map_vs_python():
+    """round-2 oracle additions against first principles: batch_inversion (fields/mod.rs:412-442) with zeros in the batch,
+    evaluate_all_lagrange_coefficients (domain.rs:183-219) outside and inside the domain (L_i(tau) = (tau^N - 1) w^i / (N (tau - w^i))),
+    and the SAP witness map (gm17/r1cs_to_sap.rs:191-240) against the same steps on Python integers"""
+    for field in ("mnt4753_fr", "mnt6753_fr"):
+        F = S.FIELD_OF[field]
+        p = F.p
+        rng = pyref.Rng(17)
+        vals = [rng.field_elem(p) for _ in range(41)]
+        vals[0] = vals[7] = vals[40] = 0
+        assert S.fe_list(F, S.oracle_batch_inversion(field, S.fe_array(F, vals))) == [0 if v == 0 else pow(v, -1, p) for v in vals]
+        log_n = 5
+        n = 1 << log_n
+        w = pyref.domain_params(F, log_n)
+        tau = rng.field_elem(p)
+        tn = pow(tau, n, p)
+        exp = [(tn - 1) * pow(n, -1, p) % p * pow(w, i, p) % p * pow((tau - pow(w, i, p)) % p, -1, p) % p for i in range(n)]
+        assert S.fe_list(F, S.oracle_lagrange(field, log_n, S.fe_array(F, [tau])[0])) == exp
+        assert sum(exp) % p == 1                                                    # the Lagrange basis sums to one
+        assert S.fe_list(F, S.oracle_lagrange(field, log_n, S.fe_array(F, [pow(w, 9, p)])[0])) == [1 if i == 9 else 0 for i in range(n)]
+        av, cv = [rng.field_elem(p) for _ in range(n)], [rng.field_elem(p) for _ in range(n)]
+        d1, d2 = rng.field_elem(p), rng.field_elem(p)
+        ac = pyref.ntt_fast(F, av, log_n, inverse=True)
+        hh = [2 * d1 * x % p for x in ac]
+        hh[0] = (hh[0] - d2 - d1 * d1) % p
+        hh.append(d1 * d1 % p)
+        ae = pyref.ntt_fast(F, ac, log_n, coset=True)
+        ce = pyref.ntt_fast(F, pyref.ntt_fast(F, cv, log_n, inverse=True), log_n, coset=True)
+        vi = pow((pow(F.generator, n, p) - 1) % p, -1, p)
+        q = pyref.ntt_fast(F, [(x * x - y) * vi % p for x, y in zip(ae, ce)], log_n, inverse=True, coset=True)
+        for i in range(n - 1):
+            hh[i] = (hh[i] + q[i]) % p
+        got = S.oracle_sap_witness_map(field, S.fe_array(F, av), S.fe_array(F, cv), S.fe_array(F, [d1])[0], S.fe_array(F, [d2])[0], 2)
+        assert S.fe_list(F, got) == hh
