@@ -80,23 +80,19 @@ def main():
         sys.exit(2)
     dist = None
     cdist = None
+    # The contract is ONE JSON line on stdout, but gloo ("[Gloo] Rank r is connected ...") and RCCL (its version banner)
+    # write to file descriptor 1 from native code: point fd 1 at stderr for the whole run and keep the real stdout aside.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     # Rendezvous, barrier and the max over ranks go over gloo (CPU); the data path -- the one exchange of partial sums --
     # is the library's own RCCL communicator behind the C ABI (include/ginger_hip_dist.h), so torch's RCCL is never loaded.
     # GH_DIST_BACKEND=gloo rehearses the N > 1 path on a one-GPU box (ranks share the card, the exchange goes over gloo).
     backend = os.environ.get("GH_DIST_BACKEND", "rccl")
     if world > 1:
         import torch.distributed as dist
-        # gloo prints its "[Gloo] Rank r is connected ..." lines on stdout; the contract is ONE JSON line there
-        sys.stdout.flush()
-        saved = os.dup(1)
-        os.dup2(2, 1)
-        try:
-            dist.init_process_group("gloo")
-            dist.barrier()
-        finally:
-            sys.stdout.flush()
-            os.dup2(saved, 1)
-            os.close(saved)
+        dist.init_process_group("gloo")
+        dist.barrier()
 
     import pyref
     from __graft_entry__ import _load_pkg
@@ -105,13 +101,38 @@ def main():
     distmod = importlib.import_module("ginger_lib_amd.dist")
     # raises if the HIP library or a gfx950 device is missing: no fallback.  (gloo rehearsal on a one-GPU
     # box: let the library map LOCAL_RANK modulo the device count.)
-    gl.init(local_rank if (world == 1 or backend == "rccl") else None)
+    share_card = backend != "rccl"
+    if world > 1 and not share_card:
+        import torch
+        share_card = torch.cuda.device_count() < world      # fewer cards than ranks (a rehearsal): RCCL will refuse, see below
+    gl.init(None if (world > 1 and share_card) else local_rank)
+    exchange_note = None
     if world > 1:
+        def _callback_transport():
+            return distmod.CDist(gl, rank, world, transport="callback", allgather=distmod.gloo_allgather_bytes(dist))
         if backend == "rccl":
             from torch.distributed.distributed_c10d import _get_default_store
-            cdist = distmod.CDist(gl, rank, world, transport="rccl", store=_get_default_store())
+            import torch
+            # bring the communicator up and push one exchange of the identity through it; every rank then agrees (over gloo)
+            # whether RCCL is usable.  If any rank saw an error the whole job drops to the callback transport, and says so.
+            err = ""
+            try:
+                cdist = distmod.CDist(gl, rank, world, transport="rccl", store=_get_default_store())
+                ident = np.zeros(36 * pyref.CURVES[args.curve].deg, dtype=np.uint64)
+                ident[12 * pyref.CURVES[args.curve].deg] = 1          # (0 : 1 : 0); any limbs do for the probe
+                cdist.allgather_fold(args.curve, ident)
+            except Exception as e:      # noqa: reported below
+                err = "%s: %s" % (type(e).__name__, e)
+            flag = torch.tensor([0 if err else 1])
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                sys.stderr.write("bench.py rank %d: RCCL exchange unavailable (%s); using the gloo callback transport\n" % (rank, err or "another rank failed"))
+                if cdist is not None:
+                    cdist.shutdown()
+                cdist = _callback_transport()
+                exchange_note = "gloo callback (RCCL failed: %s)" % (err or "on another rank")
         else:
-            cdist = distmod.CDist(gl, rank, world, transport="callback", allgather=distmod.gloo_allgather_bytes(dist))
+            cdist = _callback_transport()
     if args.window:
         gl.msm_set_window(args.window)
 
@@ -280,7 +301,7 @@ def main():
         "pipelined": not args.no_pipeline,
     }
     if world > 1:
-        out["exchange"] = {"transport": "rccl all-gather behind gh_partials_allgather_fold" if backend == "rccl" else "gloo (rehearsal)",
+        out["exchange"] = {"transport": exchange_note or ("rccl all-gather behind gh_partials_allgather_fold" if backend == "rccl" else "gloo (rehearsal)"),
                            "ranks_seen_by_transport": cdist.world_seen, "bytes_per_rank": 288 * C.deg,
                            "avg_us": float(np.mean(exch_us[-args.steps:])) if exch_us else None}
     if plain is not None:
@@ -403,7 +424,7 @@ def main():
     rb.free()
     ds.free()
     if rank == 0:
-        print(json.dumps(out))
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if world > 1:
         cdist.shutdown()
         dist.destroy_process_group()

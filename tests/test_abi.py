@@ -62,3 +62,27 @@ def test_compute_fails_loudly_without_gpu(gl):
         gl.VariableBaseMSM.multi_scalar_mul("mnt4753_g1", np.zeros((1, 24), np.uint64), np.zeros((1, 12), np.uint64))
     with pytest.raises(gl.GingerHipError):
         gl.EvaluationDomain("mnt4753_fr", 4).fft(np.zeros((4, 12), np.uint64))
+
+
+def test_long_branch_guard_rules():
+    """tools/check_long_branches.py (the build-time guard against the hipcc relaxed-branch hang): its two
+    rules on hand-made listings -- a leaf callee clobbering s[30:31] is flagged, a callee that saved s30 first and a kernel are not"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("clb", os.path.join(ROOT, "tools", "check_long_branches.py"))
+    clb = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(clb)
+    dis = "\n".join([
+        "0000000000001000 <leaf_fn>:", "\ts_getpc_b64 s[30:31]  // 1000", "\ts_setpc_b64 s[30:31]",
+        "0000000000002000 <nonleaf_fn>:", "\tv_writelane_b32 v254, s30, 0", "\ts_getpc_b64 s[30:31]", "\ts_swappc_b64 s[30:31], s[30:31]",
+        "0000000000003000 <other_pair>:", "\ts_getpc_b64 s[46:47]"])
+    fns = dict(clb.functions(dis))
+    assert set(fns) == {"leaf_fn", "nonleaf_fn", "other_pair"} and len(fns["leaf_fn"]) == 2
+    assert len(clb.scan_callee("leaf_fn", fns["leaf_fn"], 64)) == 1
+    assert clb.scan_callee("nonleaf_fn", fns["nonleaf_fn"], 300000) == []
+    assert clb.scan_callee("other_pair", fns["other_pair"], 64) == []
+    assert len(clb.scan_callee("other_pair", fns["other_pair"], 200000)) == 1          # a leaf above the relaxation size
+    # and on the built library, when there is one: no finding
+    lib = os.path.join(ROOT, "ginger-lib_amd", "libginger_hip.so")
+    if os.path.exists(lib):
+        found, n_funcs, n_kernels, _ = clb.check(lib)
+        assert found == [] and n_kernels > 50 and n_funcs > n_kernels
