@@ -11,13 +11,17 @@
 #include "host_math.h"
 
 #ifndef GH_F3S_TRIPLE
-#define GH_F3S_TRIPLE 0   // Fq3 accumulation: 0 = three plain products in a rolled loop, 2 waves/SIMD; 1 = triple product with one
-                         // reduction (fp_mul3, host-tested), unrolled, 1 wave/SIMD -- hipcc did not finish that kernel in 25 minutes
+#define GH_F3S_TRIPLE 2   // Fq3 tower product in the projective accumulation / reduction kernels (F3S in msm_kernels.h):
+                          //   0 = three plain products in a rolled loop (three reductions, 4056 mads), 2 waves/SIMD
+                          //   1 = triple product with ONE reduction (fp_mul3, 2704 mads) inlined at every site: hipcc did not finish
+                          //       that kernel in 25 minutes (eleven sites) -- kept for the record
+                          //   2 = the same triple product as ONE out-of-line device function (f3s_mul_outlined): compiles in seconds;
+                          //       2^19 pairs: projective accumulation 222 -> 167 ms, bucket reduction 17.4 -> 13.6 ms
 #endif
 #ifndef GH_AFF_F3S_TRIPLE
-#define GH_AFF_F3S_TRIPLE 0   // Fq3 affine rounds: 1 = the three products of a lane as one triple product with a single reduction
-                              // (fp_mul3, 2704 mads instead of 4056) -- hipcc had not finished the two round kernels after 36
-                              // CPU-minutes; 0 = three plain products in a rolled loop
+#define GH_AFF_F3S_TRIPLE 2   // the same choice for the Fq3 affine rounds: 0 = rolled (2^19 pairs: rounds + finish 133 ms), 1 = inlined
+                              // triple product (not compiled after 70 CPU-minutes), 2 = out-of-line triple product at one wave per
+                              // SIMD (98 ms; at two waves per SIMD, GH_F3S_CALL_WAVES=2, the caller spills 1.4 KB: 140 ms)
 #endif
 #ifndef GH_F2S_DUAL
 #define GH_F2S_DUAL 1   // Fq2 accumulation: 1 = dual product at 1 wave/SIMD (119 ms at 2^20 pairs); 0 = two plain products per
@@ -507,7 +511,7 @@ struct MsmJob {
             constexpr bool is_g2 = std::is_same<C, Mnt4G2>::value || std::is_same<C, Mnt6G2>::value;
             if constexpr (is_g2) {
                 if (!no_split) {
-                    typedef typename std::conditional<std::is_same<C, Mnt4G2>::value, F2S<P4, 13, GH_F2S_DUAL != 0>, F3S<P6, 11, GH_F3S_TRIPLE != 0>>::type FS;
+                    typedef typename std::conditional<std::is_same<C, Mnt4G2>::value, F2S<P4, 13, GH_F2S_DUAL != 0>, F3S<P6, 11, GH_F3S_TRIPLE>>::type FS;
                     constexpr int LANES = FS::LANES;
                     const size_t waves = (tasks + (64 / LANES) - 1) / (64 / LANES);
                     hipLaunchKernelGGL((msm_accumulate_split_kernel<C, FS, LANES>), dim3((unsigned)((waves * 64 + 255) / 256)), dim3(256), 0, st,
@@ -547,7 +551,7 @@ struct MsmJob {
     // the single-reduction triple product (Fq3: six product sites per addition, where the projective kernel's eleven did
     // not get through hipcc unrolled)
     typedef typename std::conditional<C::F::DEG == 1, F1S<typename C::PF>,
-            typename std::conditional<C::F::DEG == 2, F2S<P4, 13, true>, F3S<P6, 11, GH_AFF_F3S_TRIPLE != 0>>::type>::type TreeFS;
+            typename std::conditional<C::F::DEG == 2, F2S<P4, 13, true>, F3S<P6, 11, GH_AFF_F3S_TRIPLE>>::type>::type TreeFS;
 
     int launch_tree(hipStream_t st) {
         typedef TreeFS FS;
@@ -679,7 +683,7 @@ struct MsmJob {
                                    (const uint32_t*)nullptr, stR, mR, (const uint32_t*)nullptr, nbk, (const Aff<C>*)salts, buckets,
                                    (const uint32_t*)nullptr, 0u, 0u, heavy_chunk, (Proj<C>*)nullptr, bq[j], T(j, R));
             } else {
-                typedef typename std::conditional<C::F::DEG == 2, F2S<P4, 13, GH_F2S_DUAL != 0>, F3S<P6, 11, GH_F3S_TRIPLE != 0>>::type FA;
+                typedef typename std::conditional<C::F::DEG == 2, F2S<P4, 13, GH_F2S_DUAL != 0>, F3S<P6, 11, GH_F3S_TRIPLE>>::type FA;
                 const size_t fwaves = ((size_t)nbk + TPW - 1) / TPW;
                 hipLaunchKernelGGL((msm_accumulate_split_kernel<C, FA, LANES, true>), dim3((unsigned)((fwaves * 64 + 255) / 256)), dim3(256), 0, st,
                                    (const Aff<C>*)in, (const uint32_t*)nullptr, stR, mR, (const uint32_t*)nullptr, nbk, (const Aff<C>*)salts, buckets,
@@ -706,7 +710,7 @@ struct MsmJob {
         bool launched = false;
         if constexpr (C::F::DEG >= 2) {
             if (tpw != 64) {
-                typedef typename std::conditional<C::F::DEG == 2, F2S<P4, 13>, F3S<P6, 11>>::type FS;
+                typedef typename std::conditional<C::F::DEG == 2, F2S<P4, 13>, F3S<P6, 11, GH_F3S_TRIPLE>>::type FS;
                 constexpr int LANES = FS::LANES, TPW = C::F::DEG == 2 ? 32 : 16;
                 const size_t lds_split = 64 * sizeof(P3);
                 hipLaunchKernelGGL((msm_wave_reduce_split_kernel<C, FS, LANES, TPW>), dim3(nb1), dim3(64), lds_split, st,

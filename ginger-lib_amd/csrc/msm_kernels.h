@@ -593,13 +593,44 @@ template <class P, int NR, bool DUAL = true> struct F2S {
 // Fq3 = Fp[X]/(X^3 - NR) over lane triples (lanes 3g, 3g+1, 3g+2 hold c0, c1, c2; lane 63 of a wave
 // idles).  Schoolbook, three Fp products per lane:
 //   c_j = sum_{m <= j} a_(j-m) b_m + NR sum_{m > j} a_(j-m+3) b_m
-// TRIPLE = true: the three products of a lane as ONE triple product with a single reduction (fp_mul3: 2704
-// mads, unrolled, 1 wave / SIMD); false: three plain products in a rolled loop (4056 mads, 2 waves / SIMD).
-template <class P, int NR, bool TRIPLE = false> struct F3S {
+// TRIPLE = 0: three plain products in a rolled loop (4056 mads, 2 waves / SIMD); 1: ONE triple product with a single
+// reduction (fp_mul3: 2704 mads) inlined at every site (1 wave / SIMD; hipcc does not get through it); 2: that triple
+// product as one out-of-line function (GH_F3S_CALL_WAVES waves / SIMD) -- the default, see msm_impl.h.
+// The tower product of a lane triple as ONE out-of-line device function (F3S mode 2): lane rotations, the two NR multiples,
+// the operand selection and the triple product with its single reduction.  One body per kernel instead of one per
+// product site, which is what lets hipcc get through the kernels at all (mode 1, the same code inlined at every site,
+// had not compiled after an hour).  Two Fp arguments and an Fp result travel in VGPRs / on the stack.
+#ifndef GH_F3S_CALL_WAVES
+#define GH_F3S_CALL_WAVES 1
+#endif
+template <class P, int NR> __device__ __attribute__((noinline)) Fp f3s_mul_outlined(Fp a, Fp b) {
+    const int lane = threadIdx.x & 63, j = lane % 3, base = lane - j;
+    const int s1 = base + (j + 1) % 3, s2 = base + (j + 2) % 3;
+    Fp an, ap, bn, bp;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        an.l[i] = (uint32_t)__shfl((int)a.l[i], s1); ap.l[i] = (uint32_t)__shfl((int)a.l[i], s2);
+        bn.l[i] = (uint32_t)__shfl((int)b.l[i], s1); bp.l[i] = (uint32_t)__shfl((int)b.l[i], s2);
+    }
+    // c_j = a_j b_0 + [NR if j = 0] a_(j-1) b_1 + [NR if j < 2] a_(j-2) b_2     (indices mod 3)
+    const Fp apn = fp_mul_small<P, NR>(ap), ann = fp_mul_small<P, NR>(an);
+    Fp x2, x3, y1, y2, y3;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        x2.l[i] = j == 0 ? apn.l[i] : ap.l[i];
+        x3.l[i] = j < 2 ? ann.l[i] : an.l[i];
+        y1.l[i] = j == 0 ? b.l[i] : (j == 1 ? bp.l[i] : bn.l[i]);
+        y2.l[i] = j == 0 ? bn.l[i] : (j == 1 ? b.l[i] : bp.l[i]);
+        y3.l[i] = j == 0 ? bp.l[i] : (j == 1 ? bn.l[i] : b.l[i]);
+    }
+    return fp_mul3<P>(a, y1, x2, y2, x3, y3);
+}
+
+template <class P, int NR, int TRIPLE = 0> struct F3S {
     typedef Fp T;
     static constexpr int DEG = 1;
     static constexpr int LANES = 3;
-    static constexpr int WAVES = TRIPLE ? 1 : 2;
+    static constexpr int WAVES = TRIPLE == 1 ? 1 : (TRIPLE == 2 ? GH_F3S_CALL_WAVES : 2);
     static __device__ __forceinline__ int comp() { return (int)((threadIdx.x & 63u) % 3u); }
     static __device__ __forceinline__ T rot(const T& a, int by) {   // coefficient held by lane (comp + by) mod 3 of this triple
         const int lane = threadIdx.x & 63, j = lane % 3, src = lane - j + (j + by) % 3;
@@ -624,7 +655,8 @@ template <class P, int NR, bool TRIPLE = false> struct F3S {
     // unrolled the kernel held 33 inlined products and hipcc needed more than half an hour for it.
     //   iteration m:  lane j takes a_((j - m) mod 3) * b_m, times NR when m > j (the wrapped terms)
     static __device__ __forceinline__ T mul(const T& a, const T& b) {
-        if constexpr (TRIPLE) {
+        if constexpr (TRIPLE == 2) return f3s_mul_outlined<P, NR>(a, b);
+        if constexpr (TRIPLE == 1) {
             // c_j = a_j b_0 + [NR if j = 0] a_(j-1) b_1 + [NR if j < 2] a_(j-2) b_2     (indices mod 3)
             const int j = comp();
             const T an = rot(a, 1), ap = rot(a, 2), bn = rot(b, 1), bp = rot(b, 2);
