@@ -527,7 +527,7 @@ msm_accumulate_kernel(const Aff<C>* __restrict__ bases, const uint32_t* __restri
 // products nor scratch (the call-based Fq2 kernel moved ~16 KB of scratch per mixed addition
 // and was bandwidth bound).  Products use the schoolbook split, two Fp products per lane:
 //   even lane: c0 = a0 b0 + NR a1 b1        odd lane: c1 = a1 b0 + a0 b1
-// with the partner's coefficients fetched by a lane swap (26 DPP moves per operand).
+// with the partner's coefficients fetched by DPP quad permutes (26 moves per operand: swap, broadcast of either half).
 // 22 Fp-product times per mixed addition and lane pair, against 31 on one lane -- but in registers.
 // DUAL = true: one dual product with a single reduction per lane (2028 mads, 4 operands + 2 accumulators live:
 // 512 registers, 1 wave / SIMD); DUAL = false: two plain products per lane (2704 mads, the register footprint
@@ -541,8 +541,8 @@ template <class P, int NR, bool DUAL = true> struct F2S {
     static __device__ __forceinline__ T swap(const T& a) {
         T r;
 #pragma unroll
-        for (int i = 0; i < NL; i++) r.l[i] = (uint32_t)__shfl_xor((int)a.l[i], 1);
-        return r;
+        for (int i = 0; i < NL; i++) r.l[i] = (uint32_t)__builtin_amdgcn_mov_dpp((int)a.l[i], 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+        return r;                                                     // (__shfl_xor(x, 1) compiles to ds_bpermute_b32: LDS round trips)
     }
     static __device__ __forceinline__ T sel(bool c, const T& x, const T& y) {   // c ? x : y
         T r;
@@ -556,16 +556,22 @@ template <class P, int NR, bool DUAL = true> struct F2S {
     static __device__ __forceinline__ T sub(const T& a, const T& b) { return fp_sub<P>(a, b); }
     static __device__ __forceinline__ T dbl(const T& a) { return fp_dbl<P>(a); }
     static __device__ __forceinline__ T neg(const T& a) { return fp_neg<P>(a); }
+    // coefficient PART (0 / 1) of b in both lanes of the pair: one DPP move per limb (quad_perm [0,0,2,2] / [1,1,3,3])
+    template <int PART> static __device__ __forceinline__ T bcast(const T& b) {
+        T r;
+#pragma unroll
+        for (int i = 0; i < NL; i++) r.l[i] = (uint32_t)__builtin_amdgcn_mov_dpp((int)b.l[i], PART ? 0xF5 : 0xA0, 0xF, 0xF, true);
+        return r;
+    }
     static __device__ __forceinline__ T mul(const T& a, const T& b) {
         const bool o = odd();
-        const T ao = swap(a), bo = swap(b);
         // per lane:  even: a0 b0 + (NR a1) b1      odd: a1 b0 + a0 b1
+        // = own a times b0, the partner's a (times NR on the even lane: fp_mul_small_rt with k = NR / 1) times b1
+        const T ao = fp_mul_small_rt<P>(swap(a), o ? 1u : (uint32_t)NR), b0 = bcast<0>(b), b1 = bcast<1>(b);
         if constexpr (DUAL) {
-            return fp_mul2<P>(a, sel(o, bo, b), sel(o, ao, fp_mul_small<P, NR>(ao)), sel(o, b, bo));
+            return fp_mul2<P>(a, b0, ao, b1);
         } else {
-            const T t1 = fp_mul<P>(a, sel(o, bo, b));
-            const T t2 = fp_mul<P>(sel(o, ao, fp_mul_small<P, NR>(ao)), sel(o, b, bo));
-            return fp_add<P>(t1, t2);
+            return fp_add<P>(fp_mul<P>(a, b0), fp_mul<P>(ao, b1));
         }
     }
     static __device__ __forceinline__ T mul_sub_mul(const T& a, const T& b, const T& c, const T& d) { return sub(mul(a, b), mul(c, d)); }
@@ -606,23 +612,16 @@ template <class P, int NR, bool DUAL = true> struct F2S {
 template <class P, int NR> __device__ __attribute__((noinline)) Fp f3s_mul_outlined(Fp a, Fp b) {
     const int lane = threadIdx.x & 63, j = lane % 3, base = lane - j;
     const int s1 = base + (j + 1) % 3, s2 = base + (j + 2) % 3;
-    Fp an, ap, bn, bp;
+    // c_j = a_j b_0 + [NR if j = 0] a_(j-1) b_1 + [NR if j < 2] a_(j-2) b_2     (indices mod 3): b_0, b_1, b_2 are the same
+    // for the three lanes (broadcasts within the triple); the NR multiples by fp_mul_small_rt with k = NR / 1 per lane
+    Fp an, ap, y1, y2, y3;
 #pragma unroll
     for (int i = 0; i < NL; i++) {
         an.l[i] = (uint32_t)__shfl((int)a.l[i], s1); ap.l[i] = (uint32_t)__shfl((int)a.l[i], s2);
-        bn.l[i] = (uint32_t)__shfl((int)b.l[i], s1); bp.l[i] = (uint32_t)__shfl((int)b.l[i], s2);
+        y1.l[i] = (uint32_t)__shfl((int)b.l[i], base); y2.l[i] = (uint32_t)__shfl((int)b.l[i], base + 1);
+        y3.l[i] = (uint32_t)__shfl((int)b.l[i], base + 2);
     }
-    // c_j = a_j b_0 + [NR if j = 0] a_(j-1) b_1 + [NR if j < 2] a_(j-2) b_2     (indices mod 3)
-    const Fp apn = fp_mul_small<P, NR>(ap), ann = fp_mul_small<P, NR>(an);
-    Fp x2, x3, y1, y2, y3;
-#pragma unroll
-    for (int i = 0; i < NL; i++) {
-        x2.l[i] = j == 0 ? apn.l[i] : ap.l[i];
-        x3.l[i] = j < 2 ? ann.l[i] : an.l[i];
-        y1.l[i] = j == 0 ? b.l[i] : (j == 1 ? bp.l[i] : bn.l[i]);
-        y2.l[i] = j == 0 ? bn.l[i] : (j == 1 ? b.l[i] : bp.l[i]);
-        y3.l[i] = j == 0 ? bp.l[i] : (j == 1 ? bn.l[i] : b.l[i]);
-    }
+    const Fp x2 = fp_mul_small_rt<P>(ap, j == 0 ? (uint32_t)NR : 1u), x3 = fp_mul_small_rt<P>(an, j < 2 ? (uint32_t)NR : 1u);
     return fp_mul3<P>(a, y1, x2, y2, x3, y3);
 }
 

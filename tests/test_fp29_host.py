@@ -67,6 +67,22 @@ def test_field_ops(shim, fid, F):
 
 
 @pytest.mark.parametrize("fid,F", [(4, pyref.P4), (6, pyref.P6)])
+def test_mul_small_quotient_edges(shim, fid, F):
+    """fp_mul_small's one-pass form estimates q = floor(K x / p) from the top limb: inputs on either side of every multiple of p / K,
+    smallest and largest top limbs"""
+    p = F.p
+    out = (U * 24)()
+    for op, K in ((8, 11), (9, 13)):
+        xs = [0, 1, p - 1, p - 2, (1 << 725) - 1, 1 << 725, (p >> 725) << 725, ((p >> 725) << 725) - 1]
+        for j in range(1, K):
+            xs += [(j * p) // K + d for d in (-2, -1, 0, 1, 2)]
+        for x in xs:
+            x %= p
+            shim.t_fp_op(fid, op, words(x), words(0), out)
+            assert toint(out) == K * x % p, (K, hex(x))
+
+
+@pytest.mark.parametrize("fid,F", [(4, pyref.P4), (6, pyref.P6)])
 def test_field_inverse_safegcd(shim, fid, F):
     """fp_inv / fp_inv_plain (Bernstein-Yang divsteps, 61 batches of 29) against Python's pow(x, -1, p):
     random values, small and large ones, powers of two, and 0 -> 0 (fp_768.rs:551-554 returns None there)."""
