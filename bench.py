@@ -53,6 +53,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ntt", action="store_true")
     ap.add_argument("--no-2p24", action="store_true", help="skip the extra 2^24-pair object (BASELINE config 3's second size)")
+    ap.add_argument("--no-g2", action="store_true", help="skip the extra G2 objects (MNT4-753 G2 2^20, MNT6-753 G2 2^19)")
     ap.add_argument("--curve", default="mnt4753_g1", choices=["mnt4753_g1", "mnt4753_g2", "mnt6753_g1", "mnt6753_g2"])
     ap.add_argument("--total-log-n", type=int, default=0,
                     help="strong scaling (BASELINE config 4): 2^total-log-n pairs in all, 2^total-log-n / N per GPU; overrides --log-n")
@@ -349,6 +350,37 @@ def main():
             gl.dev_trim()
         except gl.GingerHipError as e:          # e.g. not enough HBM next to another tenant: the object is absent, the line stands
             out["msm_2p24"] = {"error": str(e)}
+
+    # ---- G2 (the prover's b_g2 MSM: BASELINE configs 4 / 5 shapes), one MSM at a time and as a pipelined batch of three
+    if not args.no_g2 and rank == 0 and world == 1 and curve == "mnt4753_g1" and not args.window:
+        out["g2"] = {}
+        for crv, lg in (("mnt4753_g2", 20), ("mnt6753_g2", 19)):
+            try:
+                ng = 1 << lg
+                Cg = pyref.CURVES[crv]
+                rbg = chain_key(crv, ng, 31)
+                dg = gl.DeviceBuffer(ng * 96).upload(S.random_scalars_np(ng, seed=4242, below=Cg.order))
+                t1 = time.perf_counter()
+                cg = rbg.precompute(0)
+                build_s = time.perf_counter() - t1
+                rbg.msm_dev(dg, ng)
+                t1 = time.perf_counter()
+                rbg.msm_dev(dg, ng)
+                rbg.msm_dev(dg, ng)
+                one_ms = (time.perf_counter() - t1) / 2 * 1e3
+                gtm = gl.msm_last_timing()
+                t1 = time.perf_counter()
+                gl.msm_batch_dev([(rbg, dg, ng)] * 3)
+                bt_ms = (time.perf_counter() - t1) * 1e3 / 3
+                out["g2"][crv] = {"workload": "%s VariableBaseMSM, 2^%d pairs, resident key with shift table" % (crv, lg),
+                                  "value": ng / bt_ms * 1e3, "unit": "scalar-muls/s", "ms_per_msm_pipelined": bt_ms, "single_msm_ms": one_ms,
+                                  "window_bits": cg, "table_build_s": build_s, "bucket_sums": "affine rounds (aff_kernels.h) + projective finish" if os.environ.get("GH_AFFINE", "2") != "0" else "projective mixed additions",
+                                  "phases_ms": {k: gtm[k] for k in ("sort_ms", "accumulate_ms", "reduce_ms", "fold_ms") if k in gtm}}
+                dg.free()
+                rbg.free()
+                gl.dev_trim()
+            except gl.GingerHipError as e:
+                out["g2"][crv] = {"error": str(e)}
 
     # ---- NTT (single GPU per rank; reported from rank 0)
     if not args.no_ntt and rank == 0:

@@ -19,6 +19,8 @@ rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_AC
     -d "$R/$OUT/sq_g1" -o run -- $P mnt4753_g1 20 1 1 2 nocheck > "$R/$OUT/sq_g1.log" 2>&1 || exit 1
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU --output-format csv \
     -d "$R/$OUT/sq_g2" -o run -- $P mnt4753_g2 20 1 1 2 nocheck > "$R/$OUT/sq_g2.log" 2>&1 || exit 1
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU --output-format csv \
+    -d "$R/$OUT/sq_g2m6" -o run -- $P mnt6753_g2 19 1 1 2 nocheck > "$R/$OUT/sq_g2m6.log" 2>&1 || exit 1
 cd "$R"
 python3 tools/make_traffic_json.py "$OUT/pmc_traffic.json" \
   "mnt4753_g1_2p20:$OUT/g1_FETCH_SIZE/run_counter_collection.csv:$OUT/g1_WRITE_SIZE/run_counter_collection.csv:21:projective mixed additions" \
