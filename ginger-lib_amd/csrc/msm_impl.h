@@ -23,6 +23,10 @@
                               // triple product (not compiled after 70 CPU-minutes), 2 = out-of-line triple product at one wave per
                               // SIMD (98 ms; at two waves per SIMD, GH_F3S_CALL_WAVES=2, the caller spills 1.4 KB: 140 ms)
 #endif
+#ifndef GH_AFF_F2S_DUAL
+#define GH_AFF_F2S_DUAL 1   // Fq2 affine rounds: 1 = dual product, one wave per SIMD (2^20 pairs: 68 ms); 0 = two plain products, two waves
+                            // per SIMD (784 B of spills: 91 ms)
+#endif
 #ifndef GH_F2S_DUAL
 #define GH_F2S_DUAL 1   // Fq2 accumulation: 1 = dual product at 1 wave/SIMD (119 ms at 2^20 pairs); 0 = two plain products per
                         // lane at 2 waves/SIMD, measured 166 ms (1.8 KB of spills: both shuffled operand sets stay live)
@@ -551,7 +555,7 @@ struct MsmJob {
     // the single-reduction triple product (Fq3: six product sites per addition, where the projective kernel's eleven did
     // not get through hipcc unrolled)
     typedef typename std::conditional<C::F::DEG == 1, F1S<typename C::PF>,
-            typename std::conditional<C::F::DEG == 2, F2S<P4, 13, true>, F3S<P6, 11, GH_AFF_F3S_TRIPLE>>::type>::type TreeFS;
+            typename std::conditional<C::F::DEG == 2, F2S<P4, 13, GH_AFF_F2S_DUAL != 0>, F3S<P6, 11, GH_AFF_F3S_TRIPLE>>::type>::type TreeFS;
 
     int launch_tree(hipStream_t st) {
         typedef TreeFS FS;
