@@ -438,7 +438,7 @@ msm_accumulate_kernel(const Aff<C>* __restrict__ bases, const uint32_t* __restri
     // addition; in between it is parked in LDS (G1 only, 26 KiB per block, word-major so lanes
     // hit distinct banks) -- that is the difference between fitting the 256-register budget and
     // spilling to scratch.
-    constexpr bool PARK = (F::DEG == 1);
+    constexpr bool PARK = (F::DEG == 1) && WAVES >= 2;
     __shared__ uint32_t park[PARK ? NL : 1][PARK ? 256 : 1];
     Proj<C> acc = proj_zero<C>();
     uint32_t k = 0;
@@ -474,6 +474,23 @@ msm_accumulate_kernel(const Aff<C>* __restrict__ bases, const uint32_t* __restri
                 phase = 1;
                 continue;
             }
+            if constexpr (WAVES == 1) {
+                // one wave per SIMD (GH_ACC_WAVES=1; not the default): no fences, independent products next to each other.
+                // 2^20 pairs: 25.6 ms against 22.4 ms for the fenced order at two waves.  Explicitly interleaved product
+                // pairs (two accumulator chains alternating statement by statement: 2.8 us per product in isolation,
+                // tools/microbench/lone_wave.hip) need more than 256 live registers here and lose the gain to
+                // AGPR copies (1.9 K v_accvgpr moves per addition): 27.3 ms.
+                u = F::sub(u, acc.y);
+                v = F::sub(v, acc.x);
+                typename F::T vv = F::sqr(v), uu = F::sqr(u);
+                typename F::T r = F::mul(vv, acc.x), vvv = F::mul(v, vv);
+                typename F::T t = F::mul(uu, acc.z), z3 = F::mul(vvv, acc.z);
+                typename F::T a = F::sub(F::sub(t, vvv), F::dbl(r));
+                typename F::T x3 = F::mul(v, a), m1 = F::mul(vvv, acc.y);
+                acc.y = F::sub(F::mul(u, F::sub(r, a)), m1);
+                acc.x = x3;
+                acc.z = z3;
+            } else {
             // operation order chosen to keep at most seven field elements live (register budget 256);
             // the scheduling fences make hipcc keep that order instead of hoisting products
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -515,6 +532,7 @@ msm_accumulate_kernel(const Aff<C>* __restrict__ bases, const uint32_t* __restri
             GH_FENCE();
             acc.z = F::mul(vvv, acc.z);
 #undef GH_FENCE
+            }
         }
         if (phase == 0 || phase == 3) { k++; phase = 0; } else phase++;
     }
