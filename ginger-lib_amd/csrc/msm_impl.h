@@ -270,8 +270,8 @@ void fold_windows(const std::vector<Proj<C>>& hw, int W, int c, int u, int sw, i
     }
 }
 
-// Merged windows (precomputed shift table): ONE bucket set of nb slots, cut into Wp pseudo-windows
-// of Q = 2^q slots for the two-level wave reduction; slot s = w' Q + k, so
+// Merged windows (precomputed shift table): ONE bucket set of nb = 2^(c-1) slots (slot s = digit magnitude s + 1), cut
+// into Wp pseudo-windows of Q = 2^q slots for the two-level wave reduction; slot s = w' Q + k, so
 //   sum_s s B_s = sum_w' R_w' + Q sum_w' w' T_w'
 // with R_w' = PW 2^(u+6) + PS 2^u + PA 2^6 + PB as above and T_w' the plain sum of pseudo-window w'.
 template <class HC>
@@ -286,6 +286,8 @@ Proj<HC> fold_merged_generic(const std::vector<Proj<HC>>& hw, int Wp, int q, int
         spb = proj_add<HC>(spb, PT(2, w, 0));
         if (w >= 1) { run = proj_add<HC>(run, PT(0, w, 0)); st = proj_add<HC>(st, run); }   // sum_w' w' T_w'
     }
+    // slot s carries digit magnitude s + 1: sum (s + 1) B_s = sum s B_s + sum_w' T_w'   (run holds T_1 + .. + T_(Wp-1) here)
+    spb = proj_add<HC>(spb, proj_add<HC>(run, PT(0, 0, 0)));
     FoldTerm<HC> t[5] = {{u + sw, &spw}, {u, &sps}, {sw, &spa}, {0, &spb}, {q, &st}};
     Proj<HC> acc = fold_terms<HC>(t, 5);
     if (proj_is_zero<HC>(acc)) acc = proj_zero<HC>();
@@ -368,7 +370,7 @@ struct MsmJob {
         // after sign folding the scalar magnitudes are below 2^752 (msm_kernels.h, digits kernel)
         W = 752 / c + 1;
         top_unsigned = (!merged && 752 % c == 0 && W >= 2) ? 1 : 0;
-        nb = (1u << (c - 1)) + 1;
+        nb = (1u << (c - 1)) + (merged ? 0u : 1u);   // merged: slot = |digit| - 1 (msm_kernels.h, digits kernel), weight slot + 1
         // bucket sets the reduction sees: W windows of nb slots, or (merged) RW pseudo-windows of Q slots
         const int q = 15;
         Q = merged ? (nb <= (1u << q) + 1 ? nb : (1u << q)) : nb;
@@ -380,7 +382,9 @@ struct MsmJob {
         // items per lane, level 1 (power of two).  The wave programs are latency chains (2 L1 + 17 steps,
         // then 2 L2 + 17): as long as the launch stays within one wave per SIMD (1024 on MI355X) a shorter
         // L1 only shortens the chain; beyond that the steps of co-resident waves add up again
-        // (measured at 2^20 buckets: L1 = 16 -> 6.2 ms, 8 -> 6.8, 4 -> 8.2, 32 -> 7.9).
+        // (measured at 2^20 + 1 buckets: L1 = 16 -> 6.2 ms, 8 -> 6.8, 4 -> 8.2, 32 -> 7.9 -- the one bucket beyond the power of two
+        //  added a 1025th / 2049th / 4097th wave program, which ran beside or after another one on its SIMD and doubled the
+        //  launch; with the merged set at exactly 2^(c-1) slots level 1 takes 4.3 ms (L1 = 16), level 2 1.1 ms).
         static const bool split_reduce_off = getenv("GH_NO_SPLIT_REDUCE") != nullptr;
         tpw = 64;
         if (C::F::DEG == 2 && !split_reduce_off) tpw = 32;     // lane pairs  (msm_kernels.h 5b)
@@ -467,7 +471,8 @@ struct MsmJob {
         HIPCHK(hipMemsetAsync(size_hist, 0, MSM_SIZE_BINS * 4, st));
         HIPCHK(hipMemsetAsync(plan, 0, 64, st));
         hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
-                           (const uint32_t*)d_scalars, (const uint8_t*)h->d_inf, n, c, W, win_stride, top_unsigned, scalar_modulus<C>(), digits, counts, agg_iters);
+                           (const uint32_t*)d_scalars, (const uint8_t*)h->d_inf, n, c, W, win_stride, top_unsigned, scalar_modulus<C>(), digits, counts, agg_iters,
+                           merged ? 1u : 0u);
         HIPCHK(hipGetLastError());
         if ((rc = device_scan(counts, starts, total, "scan_tmp"))) return rc;
         HIPCHK(hipMemcpyAsync(cursor, starts, total * 4, hipMemcpyDeviceToDevice, st));
@@ -477,7 +482,7 @@ struct MsmJob {
         hipLaunchKernelGGL(msm_heavy_plan_kernel, dim3(1), dim3(1), 0, st, (const uint32_t*)size_hist, (const uint32_t*)counts,
                            (const uint32_t*)order, (const uint32_t*)starts, (uint32_t)total, heavy_chunk, chunk_start, plan);
         hipLaunchKernelGGL(msm_scatter_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)W), dim3(256), 0, st,
-                           (const int32_t*)digits, n, W, win_stride, merged ? (uint32_t)h->n : 0u, cursor, sorted, agg_iters);
+                           (const int32_t*)digits, n, W, win_stride, merged ? (uint32_t)h->n : 0u, cursor, sorted, agg_iters, merged ? 1u : 0u);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(hplan, plan, 32, hipMemcpyDeviceToHost, st));
         HIPCHK(hipEventRecord(g.pev[slot][1], st));

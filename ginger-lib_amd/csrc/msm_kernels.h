@@ -242,9 +242,12 @@ static __device__ __forceinline__ uint32_t wave_agg_inc(uint32_t* base, uint32_t
 
 // ---------------------------------------------------------------- 1. digits + histogram
 // scalars: n x 24 words canonical (< r).  digits[w * n + i] = signed digit (0 = no contribution).
-// counts[w * win_stride + |d|] += 1; win_stride = nb = 2^(c-1) + 1 (slot 0 unused) gives every
+// counts[w * win_stride + |d| - slot_shift] += 1; win_stride = nb = 2^(c-1) + 1 (slot 0 unused, slot_shift 0) gives every
 // window its own bucket set; win_stride = 0 files all windows into ONE bucket set (precomputed
-// shift tables, section 0 below: window w then reads its bases from table row w).
+// shift tables, section 0 below: window w then reads its bases from table row w).  That merged set uses slot_shift 1:
+// slot = |d| - 1, exactly 2^(c-1) slots -- a power of two, so the bucket reduction's segments tile it without a
+// remainder (one straggling wave program on an already occupied SIMD doubled the whole launch); the weight of a slot
+// is then slot + 1 and the fold adds the plain sum of all buckets once (msm_impl.h fold_merged).
 //
 // (a) sign folding: s > r/2 is replaced by r - s with the base negated (s P = (r - s)(-P)), so the
 //     magnitude is below 2^752 and bit 752 never needs a window.
@@ -262,7 +265,7 @@ struct MsmModulus { uint32_t w[24]; };
 static __global__ void __launch_bounds__(256)
 msm_digits_kernel(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ infinity, size_t n, int c,
                   int num_windows, uint32_t win_stride, int top_unsigned, MsmModulus r,
-                  int32_t* __restrict__ digits, uint32_t* __restrict__ counts, int agg_iters) {
+                  int32_t* __restrict__ digits, uint32_t* __restrict__ counts, int agg_iters, uint32_t slot_shift) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = i < n;
     uint32_t s[25];
@@ -313,7 +316,7 @@ msm_digits_kernel(const uint32_t* __restrict__ scalars, const uint8_t* __restric
         if (skip) d = 0;
         if (valid) digits[(size_t)w * n + i] = d;
         const uint32_t mag = d < 0 ? (uint32_t)(-d) : (uint32_t)d;
-        wave_agg_inc(counts + (size_t)w * win_stride, mag, d != 0, agg_iters);
+        wave_agg_inc(counts + (size_t)w * win_stride, mag - slot_shift, d != 0, agg_iters);
     }
 }
 
@@ -378,12 +381,13 @@ static __global__ void msm_heavy_plan_kernel(const uint32_t* size_hist, const ui
 static __global__ void __launch_bounds__(256)
 msm_scatter_kernel(const int32_t* __restrict__ digits, size_t n, int num_windows, uint32_t win_stride,
                    uint32_t row_stride /* 0, or the table's row length (merged windows) */,
-                   uint32_t* __restrict__ cursor /* = copy of starts */, uint32_t* __restrict__ sorted, int agg_iters) {
+                   uint32_t* __restrict__ cursor /* = copy of starts */, uint32_t* __restrict__ sorted, int agg_iters,
+                   uint32_t slot_shift) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     int w = blockIdx.y;
     const int32_t d = i < n ? digits[(size_t)w * n + i] : 0;
     const uint32_t mag = d < 0 ? (uint32_t)(-d) : (uint32_t)d;
-    const uint32_t pos = wave_agg_inc(cursor + (size_t)w * win_stride, mag, d != 0, agg_iters);
+    const uint32_t pos = wave_agg_inc(cursor + (size_t)w * win_stride, mag - slot_shift, d != 0, agg_iters);
     if (d != 0) sorted[pos] = ((uint32_t)i + (uint32_t)w * row_stride) | (d < 0 ? 0x80000000u : 0u);
 }
 
