@@ -24,6 +24,7 @@ template <class P> static void fp_op(int op, const uint32_t* a, const uint32_t* 
         case 11: r = fp_mul_small<P, 121>(x); break;
         case 12: r = fp_inv<P>(x); break;
         case 13: r = fp_inv_plain<P>(x); break;
+        case 14: r = fp_mul_small_rt<P>(x, b[0]); break;     // multiplier (1 .. 15) in the first word of b
         default: r = fp_zero();
     }
     fp_pack(out, r);

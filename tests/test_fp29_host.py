@@ -80,6 +80,14 @@ def test_mul_small_quotient_edges(shim, fid, F):
             x %= p
             shim.t_fp_op(fid, op, words(x), words(0), out)
             assert toint(out) == K * x % p, (K, hex(x))
+    # the register-multiplier form (fp_mul_small_rt): every k it can be given, k = 1 must return x itself
+    rng = pyref.Rng(3)
+    for k in range(1, 16):
+        for x in [0, 1, p - 1, (p >> 725) << 725] + [(j * p) // k + d for j in range(1, k) for d in (-1, 0, 1)] + [rng.field_elem(p) for _ in range(4)]:
+            x %= p
+            kb = (U * 24)(*([k] + [0] * 23))
+            shim.t_fp_op(fid, 14, words(x), kb, out)
+            assert toint(out) == k * x % p, (k, hex(x))
 
 
 @pytest.mark.parametrize("fid,F", [(4, pyref.P4), (6, pyref.P6)])
