@@ -467,22 +467,64 @@ struct MsmJob {
         static const int env_agg = getenv("GH_AGG_ITERS") ? atoi(getenv("GH_AGG_ITERS")) : -1;
         const int agg_iters = env_agg >= 0 ? env_agg : 12;
         HIPCHK(hipEventRecord(g.pev[slot][0], st));
-        HIPCHK(hipMemsetAsync(counts, 0, total * 4, st));
         HIPCHK(hipMemsetAsync(size_hist, 0, MSM_SIZE_BINS * 4, st));
         HIPCHK(hipMemsetAsync(plan, 0, 64, st));
-        hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
-                           (const uint32_t*)d_scalars, (const uint8_t*)h->d_inf, n, c, W, win_stride, top_unsigned, scalar_modulus<C>(), digits, counts, agg_iters,
-                           merged ? 1u : 0u);
-        HIPCHK(hipGetLastError());
-        if ((rc = device_scan(counts, starts, total, "scan_tmp"))) return rc;
-        HIPCHK(hipMemcpyAsync(cursor, starts, total * 4, hipMemcpyDeviceToDevice, st));
+        // Bucket lists.  Large inputs: two-level counting sort with LDS atomics only (msm_kernels.h 2a); small ones: histogram +
+        // scatter with device-scope atomics (fewer launches).  GH_SORT=atomic / part forces one of them where it applies.
+        const size_t entries = (size_t)W * n;
+        static const char* env_sort = getenv("GH_SORT");
+        const uint32_t tile = entries > ((size_t)1 << 27) ? 65536u : 16384u;
+        uint32_t bin_shift = 8;
+        while (((total + ((size_t)1 << bin_shift) - 1) >> bin_shift) > (size_t)MSM_PART_MAX_BINS) bin_shift++;
+        bool part_sort = entries >= ((size_t)1 << 22) && n >= tile && bin_shift <= 13;
+        if (env_sort && !strcmp(env_sort, "atomic")) part_sort = false;
+        if (env_sort && !strcmp(env_sort, "part") && n >= tile && bin_shift <= 13) part_sort = true;
+        const bool use_part = part_sort;
+        if (use_part) {
+            MsmPartArgs a;
+            a.digits = digits; a.entries = entries; a.n = n;
+            a.win_stride = win_stride; a.row_stride = merged ? (uint32_t)h->n : 0u; a.slot_shift = merged ? 1u : 0u;
+            a.bin_shift = bin_shift; a.n_bins = (uint32_t)((total + ((size_t)1 << bin_shift) - 1) >> bin_shift);
+            a.tile = tile; a.n_blocks = (uint32_t)((entries + tile - 1) / tile);
+            const size_t cells = (size_t)a.n_bins * a.n_blocks + 1;
+            uint32_t *block_hist = nullptr, *block_off = nullptr;
+            uint2* part = nullptr;
+            char nm[48];
+            snprintf(nm, sizeof nm, "part_hist#%d", slot);
+            if ((rc = pool_get(nm, cells * 4, (void**)&block_hist))) return rc;
+            snprintf(nm, sizeof nm, "part_off#%d", slot);
+            if ((rc = pool_get(nm, cells * 4, (void**)&block_off))) return rc;
+            snprintf(nm, sizeof nm, "part_pairs#%d", slot);
+            if ((rc = pool_get(nm, entries * 8, (void**)&part))) return rc;
+            hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                               (const uint32_t*)d_scalars, (const uint8_t*)h->d_inf, n, c, W, win_stride, top_unsigned, scalar_modulus<C>(), digits,
+                               (uint32_t*)nullptr, agg_iters, merged ? 1u : 0u);
+            HIPCHK(hipMemsetAsync(block_hist + (cells - 1), 0, 4, st));
+            hipLaunchKernelGGL(msm_part_hist_kernel, dim3(a.n_blocks), dim3(MSM_PART_THREADS), 0, st, a, block_hist);
+            HIPCHK(hipGetLastError());
+            snprintf(nm, sizeof nm, "scan_tmp3#%d", slot);
+            if ((rc = device_scan(block_hist, block_off, cells, nm, st))) return rc;
+            hipLaunchKernelGGL(msm_part_scatter_kernel, dim3(a.n_blocks), dim3(MSM_PART_THREADS), 0, st, a, (const uint32_t*)block_off, part);
+            hipLaunchKernelGGL(msm_bin_sort_kernel, dim3(a.n_bins), dim3(MSM_BIN_THREADS), (size_t)4 << bin_shift, st, (const uint2*)part,
+                               (const uint32_t*)block_off, a.n_blocks, bin_shift, (uint32_t)total, counts, starts, sorted);
+            HIPCHK(hipGetLastError());
+        } else {
+            HIPCHK(hipMemsetAsync(counts, 0, total * 4, st));
+            hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                               (const uint32_t*)d_scalars, (const uint8_t*)h->d_inf, n, c, W, win_stride, top_unsigned, scalar_modulus<C>(), digits, counts, agg_iters,
+                               merged ? 1u : 0u);
+            HIPCHK(hipGetLastError());
+            if ((rc = device_scan(counts, starts, total, "scan_tmp", st))) return rc;
+            HIPCHK(hipMemcpyAsync(cursor, starts, total * 4, hipMemcpyDeviceToDevice, st));
+        }
         hipLaunchKernelGGL(msm_size_hist_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, counts, total, heavy_thr, size_hist, plan + 4);
-        if ((rc = device_scan(size_hist, size_cursor, MSM_SIZE_BINS, "scan_tmp2"))) return rc;
+        if ((rc = device_scan(size_hist, size_cursor, MSM_SIZE_BINS, "scan_tmp2", st))) return rc;
         hipLaunchKernelGGL(msm_size_scatter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, counts, total, heavy_thr, size_cursor, order);
         hipLaunchKernelGGL(msm_heavy_plan_kernel, dim3(1), dim3(1), 0, st, (const uint32_t*)size_hist, (const uint32_t*)counts,
                            (const uint32_t*)order, (const uint32_t*)starts, (uint32_t)total, heavy_chunk, chunk_start, plan);
-        hipLaunchKernelGGL(msm_scatter_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)W), dim3(256), 0, st,
-                           (const int32_t*)digits, n, W, win_stride, merged ? (uint32_t)h->n : 0u, cursor, sorted, agg_iters, merged ? 1u : 0u);
+        if (!use_part)
+            hipLaunchKernelGGL(msm_scatter_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)W), dim3(256), 0, st,
+                               (const int32_t*)digits, n, W, win_stride, merged ? (uint32_t)h->n : 0u, cursor, sorted, agg_iters, merged ? 1u : 0u);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(hplan, plan, 32, hipMemcpyDeviceToHost, st));
         HIPCHK(hipEventRecord(g.pev[slot][1], st));

@@ -316,7 +316,115 @@ msm_digits_kernel(const uint32_t* __restrict__ scalars, const uint8_t* __restric
         if (skip) d = 0;
         if (valid) digits[(size_t)w * n + i] = d;
         const uint32_t mag = d < 0 ? (uint32_t)(-d) : (uint32_t)d;
-        wave_agg_inc(counts + (size_t)w * win_stride, mag - slot_shift, d != 0, agg_iters);
+        if (counts) wave_agg_inc(counts + (size_t)w * win_stride, mag - slot_shift, d != 0, agg_iters);   // (uniform branch)
+    }
+}
+
+// ---------------------------------------------------------------- 2a. bucket lists without global atomics (large inputs)
+// The histogram + scatter pair above issues two device-scope atomics per list entry on a counter array that is
+// far larger than LDS (2 x 37.7 M at 2^20 pairs: 3.4 ms, 12 ms at 2^22).  For large inputs the lists are built by a
+// two-level counting sort whose atomics all stay in LDS:
+//   A  the bucket range is cut into NB <= 1024 bins of 2^bin_shift buckets; every block takes a tile of consecutive
+//      entries e = w n + i, counts them per bin in LDS (msm_part_hist_kernel -> block_hist[bin][block]), an exclusive
+//      scan over that array gives every (bin, block) its slice of the partitioned array, and the same tile is read
+//      again to write (bucket, list value) pairs there (msm_part_scatter_kernel);
+//   B  one block per bin: per-bucket counts in LDS, block scan -> counts[] / starts[], second sweep -> sorted[].
+// Result: the same counts / starts / sorted arrays as the atomic path (order inside a bucket is arbitrary in both).
+constexpr int MSM_PART_THREADS = 256;
+constexpr int MSM_PART_MAX_BINS = 1024;
+struct MsmPartArgs {
+    const int32_t* digits;
+    size_t entries;        // W * n
+    size_t n;
+    uint32_t win_stride, row_stride, slot_shift;
+    uint32_t bin_shift, n_bins, tile, n_blocks;
+};
+// entry e -> (bucket, value); returns false for a zero digit
+static __device__ __forceinline__ bool msm_part_entry(const MsmPartArgs& a, size_t e, uint32_t w, size_t w_base, uint32_t& bucket, uint32_t& value) {
+    const int32_t d = a.digits[e];
+    if (d == 0) return false;
+    const uint32_t mag = d < 0 ? (uint32_t)(-d) : (uint32_t)d;
+    const uint32_t i = (uint32_t)(e - w_base);
+    bucket = w * a.win_stride + (mag - a.slot_shift);
+    value = (i + w * a.row_stride) | (d < 0 ? 0x80000000u : 0u);
+    return true;
+}
+static __global__ void __launch_bounds__(MSM_PART_THREADS) msm_part_hist_kernel(MsmPartArgs a, uint32_t* __restrict__ block_hist) {
+    __shared__ uint32_t h[MSM_PART_MAX_BINS];
+    for (uint32_t i = threadIdx.x; i < a.n_bins; i += MSM_PART_THREADS) h[i] = 0;
+    __syncthreads();
+    const size_t base = (size_t)blockIdx.x * a.tile;
+    const uint32_t w0 = (uint32_t)(base / a.n);               // a tile (<= n entries) spans at most two windows
+    const size_t split = (size_t)(w0 + 1) * a.n;
+    for (uint32_t j = threadIdx.x; j < a.tile; j += MSM_PART_THREADS) {
+        const size_t e = base + j;
+        if (e >= a.entries) break;
+        const uint32_t w = e >= split ? w0 + 1 : w0;
+        uint32_t b, v;
+        if (msm_part_entry(a, e, w, (size_t)w * a.n, b, v)) atomicAdd(&h[b >> a.bin_shift], 1u);
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < a.n_bins; i += MSM_PART_THREADS) block_hist[(size_t)i * a.n_blocks + blockIdx.x] = h[i];
+}
+static __global__ void __launch_bounds__(MSM_PART_THREADS) msm_part_scatter_kernel(MsmPartArgs a, const uint32_t* __restrict__ block_off,
+                                                                                  uint2* __restrict__ part) {
+    __shared__ uint32_t cur[MSM_PART_MAX_BINS];
+    for (uint32_t i = threadIdx.x; i < a.n_bins; i += MSM_PART_THREADS) cur[i] = block_off[(size_t)i * a.n_blocks + blockIdx.x];
+    __syncthreads();
+    const size_t base = (size_t)blockIdx.x * a.tile;
+    const uint32_t w0 = (uint32_t)(base / a.n);
+    const size_t split = (size_t)(w0 + 1) * a.n;
+    for (uint32_t j = threadIdx.x; j < a.tile; j += MSM_PART_THREADS) {
+        const size_t e = base + j;
+        if (e >= a.entries) break;
+        const uint32_t w = e >= split ? w0 + 1 : w0;
+        uint32_t b, v;
+        if (msm_part_entry(a, e, w, (size_t)w * a.n, b, v)) {
+            const uint32_t pos = atomicAdd(&cur[b >> a.bin_shift], 1u);
+            part[pos] = make_uint2(b, v);
+        }
+    }
+}
+// one block per bin; dynamic LDS: 2^bin_shift counters.  block_off[bin * n_blocks] is where the bin's pairs start
+// (block_off has n_bins * n_blocks + 1 elements: the last one is the total).
+constexpr int MSM_BIN_THREADS = 1024;
+static __global__ void __launch_bounds__(MSM_BIN_THREADS) msm_bin_sort_kernel(const uint2* __restrict__ part, const uint32_t* __restrict__ block_off,
+                                                                             uint32_t n_blocks, uint32_t bin_shift, uint32_t total,
+                                                                             uint32_t* __restrict__ counts, uint32_t* __restrict__ starts,
+                                                                             uint32_t* __restrict__ sorted) {
+    extern __shared__ uint32_t cnt[];                 // 2^bin_shift
+    __shared__ uint32_t wsum[MSM_BIN_THREADS / 64];
+    const uint32_t bin = blockIdx.x, size = 1u << bin_shift, b0 = bin << bin_shift;
+    const uint32_t lo = block_off[(size_t)bin * n_blocks], hi = block_off[(size_t)(bin + 1) * n_blocks];
+    for (uint32_t i = threadIdx.x; i < size; i += MSM_BIN_THREADS) cnt[i] = 0;
+    __syncthreads();
+    for (uint32_t k = lo + threadIdx.x; k < hi; k += MSM_BIN_THREADS) atomicAdd(&cnt[part[k].x - b0], 1u);
+    __syncthreads();
+    // exclusive scan of cnt: each thread owns `per` consecutive counters
+    const uint32_t per = size / MSM_BIN_THREADS > 0 ? size / MSM_BIN_THREADS : 1;
+    const uint32_t first = threadIdx.x * per;
+    uint32_t mine = 0;
+    if (first < size) for (uint32_t k = 0; k < per; k++) mine += cnt[first + k];
+    uint32_t incl = mine;                              // wave-inclusive scan, then across the 16 waves
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int off = 1; off < 64; off <<= 1) { const uint32_t t = __shfl_up(incl, off); if (lane >= off) incl += t; }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t wbase = 0;
+    for (int k = 0; k < wave; k++) wbase += wsum[k];
+    uint32_t run = lo + wbase + incl - mine;
+    if (first < size) {
+        for (uint32_t k = 0; k < per; k++) {
+            const uint32_t c = cnt[first + k], b = b0 + first + k;
+            if (b < total) { counts[b] = c; starts[b] = run; }
+            cnt[first + k] = run;                     // becomes the bucket's cursor
+            run += c;
+        }
+    }
+    __syncthreads();
+    for (uint32_t k = lo + threadIdx.x; k < hi; k += MSM_BIN_THREADS) {
+        const uint2 pv = part[k];
+        sorted[atomicAdd(&cnt[pv.x - b0], 1u)] = pv.y;
     }
 }
 

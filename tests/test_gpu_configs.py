@@ -168,6 +168,40 @@ def test_split_kernels_heavy_buckets_batch_vs_oracle(gpu, curve, log_n):
         gpu.dev_trim()
 
 
+def test_partition_sort_path_skewed_vs_oracle(gpu):
+    """the bucket lists of large inputs come from the two-level counting sort (msm_kernels.h 2a: W n >= 2^22 entries): oracle parity
+    at 2^17 pairs with skewed scalars (zeros, ones, one value repeated thousands of times: heavy buckets, bins with a single
+    bucket holding most entries), infinity bases, per-window path and shift table, one MSM and a batch with a ragged length"""
+    curve = "mnt4753_g1"
+    C = pyref.CURVES[curve]
+    r = C.order
+    n = 1 << 17
+    bases, pool = tiled_bases(curve, n, 256, 77)
+    s = skew(S.random_scalars_np(n, seed=91, below=r), r)
+    s[1000:9000] = s[999]                                    # 8 000 equal scalars: the same bucket in every window
+    inf = np.zeros(n, dtype=np.uint8)
+    inf[5::97] = 1
+    t = S.random_scalars_np(n, seed=92, below=r)
+    exp_s = oracle_affine(curve, S.oracle_msm(curve, bases, inf, s, 16))
+    exp_t = oracle_affine(curve, S.oracle_msm(curve, bases, inf, t, 16))
+    m = n - 12345
+    exp_m = oracle_affine(curve, S.oracle_msm(curve, bases[:m], inf[:m], s[:m], 16))
+    rb = gpu.ResidentBases(curve, bases, infinity=inf)
+    ds, dt = gpu.DeviceBuffer(s.nbytes).upload(s), gpu.DeviceBuffer(t.nbytes).upload(t)
+    try:
+        for table in (False, True):
+            if table:
+                rb.precompute(0)
+            assert affine(gpu, curve, rb.msm_dev(ds, n)) == exp_s, table
+            assert gpu.msm_last_timing()["heavy_buckets"] > 0
+            outs = gpu.msm_batch_dev([(rb, dt, n), (rb, ds, m), (rb, ds, n)])
+            assert [affine(gpu, curve, o) for o in outs] == [exp_t, exp_m, exp_s], table
+    finally:
+        ds.free(); dt.free()
+        rb.free()
+        gpu.dev_trim()
+
+
 # ------------------------------------------------------------------------------ config 5 at 2^20
 def _replay(gpu, log_n, with_oracle):
     """device halves of create_proof for a 2^log_n-constraint MNT4-753 circuit (tools/prover_replay.py as a test)"""
