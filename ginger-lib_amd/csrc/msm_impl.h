@@ -327,6 +327,7 @@ struct MsmJob {
     uint32_t *counts = nullptr, *starts = nullptr, *cursor = nullptr, *sorted = nullptr, *order = nullptr, *size_hist = nullptr,
              *size_cursor = nullptr, *chunk_start = nullptr, *plan = nullptr;
     Proj<C>*buckets = nullptr, *seg_out = nullptr, *win_out = nullptr, *partials = nullptr;
+    bool solo = false;               // a batch of one (set by msm_batch): nothing runs beside this MSM
     // affine rounds (aff_kernels.h)
     bool tree = false;
     int tree_rounds = 0;
@@ -772,10 +773,30 @@ struct MsmJob {
             }
         }
         if (!launched) {
-            hipLaunchKernelGGL((msm_wave_reduce_kernel<C>), dim3((nb1 + wpb - 1) / wpb), dim3(64 * wpb), lds_wave * wpb, st,
-                               i0, none, none, nb1, 1u, segs_per_window, L1, (const Aff<C>*)salts, seg_out);
-            hipLaunchKernelGGL((msm_wave_reduce_kernel<C>), dim3((nb2 + wpb - 1) / wpb), dim3(64 * wpb), lds_wave * wpb, st,
-                               r0, r1, r2, (uint32_t)RW, 3u, 1u, L2, (const Aff<C>*)salts, win_out);
+            // the programs' accumulators live in a slab of global memory each (msm_kernels.h, ReduceSlab)
+            uint32_t* slabs = nullptr;
+            {
+                char nm[48];
+                snprintf(nm, sizeof nm, "reduce_slabs#%d", slot);
+                const size_t progs = nb1 > nb2 ? nb1 : nb2;
+                int rc = pool_get(nm, progs * ReduceSlab<C>::WORDS * 4, (void**)&slabs);
+                if (rc) return rc;
+            }
+            // A stand-alone MSM has the chip to itself: the 512-register build of the program (one wave per SIMD, 88 B of spills
+            // per lane instead of 680) -- inside a batch the reduction must fit beside the accumulation's waves (256 registers).
+            static const int env_w = getenv("GH_REDUCE_WAVES") ? atoi(getenv("GH_REDUCE_WAVES")) : 0;
+            const bool one_wave = env_w ? env_w == 1 : solo;
+            if (one_wave) {
+                hipLaunchKernelGGL((msm_wave_reduce_kernel<C, 1>), dim3((nb1 + wpb - 1) / wpb), dim3(64 * wpb), lds_wave * wpb, st,
+                                   i0, none, none, nb1, 1u, segs_per_window, L1, (const Aff<C>*)salts, seg_out, slabs);
+                hipLaunchKernelGGL((msm_wave_reduce_kernel<C, 1>), dim3((nb2 + wpb - 1) / wpb), dim3(64 * wpb), lds_wave * wpb, st,
+                                   r0, r1, r2, (uint32_t)RW, 3u, 1u, L2, (const Aff<C>*)salts, win_out, slabs);
+            } else {
+                hipLaunchKernelGGL((msm_wave_reduce_kernel<C, 2>), dim3((nb1 + wpb - 1) / wpb), dim3(64 * wpb), lds_wave * wpb, st,
+                                   i0, none, none, nb1, 1u, segs_per_window, L1, (const Aff<C>*)salts, seg_out, slabs);
+                hipLaunchKernelGGL((msm_wave_reduce_kernel<C, 2>), dim3((nb2 + wpb - 1) / wpb), dim3(64 * wpb), lds_wave * wpb, st,
+                                   r0, r1, r2, (uint32_t)RW, 3u, 1u, L2, (const Aff<C>*)salts, win_out, slabs);
+            }
         }
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(g.pev[slot][5], st));
@@ -838,6 +859,7 @@ int msm_batch(BasesBase* const* hs, const void* const* d_scalars, const size_t* 
     int rc;
     auto issue_sort = [&](int k) -> int {
         MsmJob<C>& j = jobs[(size_t)k];
+        j.solo = count == 1;
         if ((rc = j.prepare(hs[k], d_scalars[k], n_scalars[k], out_xyz + (size_t)k * out_stride, k & 1))) return rc;
         if (k >= 2) {
             HIPCHK(hipStreamWaitEvent(g.stream, g.pev[k & 1][4], 0));   // acc(k-2) has consumed this slot's lists

@@ -1063,12 +1063,75 @@ template <class C> __device__ __forceinline__ Proj<C> proj_add_sel(const Proj<C>
         __builtin_amdgcn_wave_barrier();                         \
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   \
     } while (0)
-template <class C>
-__global__ void __launch_bounds__(256, 2)
+// The same addition WITHOUT the final selects: p and q are dead after the first five products, which is what lets the step
+// fit the register budget; the caller patches the lanes with an infinite operand (pz / qz) from re-loaded operands.
+template <class C> __device__ __forceinline__ Proj<C> proj_add_raw(const Proj<C>& p, const Proj<C>& q, bool& same, bool& pz, bool& qz) {
+    typedef typename ReduceField<C>::type F;
+#define GH_RFENCE() __builtin_amdgcn_sched_barrier(0)      // keep the written order: at most eight field elements live
+    pz = F::is_zero(p.z); qz = F::is_zero(q.z);
+    typename F::T y1z2 = F::mul(p.y, q.z);
+    GH_RFENCE();
+    typename F::T u = F::sub(F::mul(p.z, q.y), y1z2);
+    GH_RFENCE();
+    typename F::T x1z2 = F::mul(p.x, q.z);
+    GH_RFENCE();
+    typename F::T v = F::sub(F::mul(p.z, q.x), x1z2);
+    GH_RFENCE();
+    typename F::T z1z2 = F::mul(p.z, q.z);                 // p, q dead
+    GH_RFENCE();
+    same = !pz && !qz && F::is_zero(u) && F::is_zero(v);
+    typename F::T vv = F::sqr(v);
+    GH_RFENCE();
+    typename F::T r = F::mul(vv, x1z2);                    // x1z2 dead
+    GH_RFENCE();
+    typename F::T vvv = F::mul(v, vv);                     // vv dead
+    GH_RFENCE();
+    typename F::T uu = F::sqr(u);
+    GH_RFENCE();
+    typename F::T a = F::sub(F::sub(F::mul(uu, z1z2), vvv), F::dbl(r));   // uu dead
+    GH_RFENCE();
+    Proj<C> o;
+    o.x = F::mul(v, a);                                    // v dead
+    GH_RFENCE();
+    o.z = F::mul(vvv, z1z2);                               // z1z2 dead
+    GH_RFENCE();
+    typename F::T t1 = F::mul(F::sub(r, a), u);            // r, a, u dead
+    GH_RFENCE();
+    o.y = F::sub(t1, F::mul(vvv, y1z2));
+#undef GH_RFENCE
+    return o;
+}
+
+// The three accumulators of a program (run, wacc, and tmp of the salt detour) live in a per-program slab of global memory,
+// word-major (slab[(slot * NW + word) * 64 + lane]: one 256-byte row per wave instruction), and only the operand of the
+// current step is in registers: with all three held in registers next to the operands of the addition the compiler
+// spilled 2.4 KB per lane -- 848 scratch instructions per step against the 156-234 explicit ones now.
+template <class C> struct ReduceSlab {
+    static constexpr int NW = (int)(sizeof(Proj<C>) / 4);
+    static constexpr size_t WORDS = (size_t)3 * NW * 64;      // per program
+    static __device__ __forceinline__ Proj<C> ld(const uint32_t* slab, int slot, int lane) {
+        Proj<C> v;
+        uint32_t* w = reinterpret_cast<uint32_t*>(&v);
+        const uint32_t* p = slab + (size_t)slot * NW * 64 + lane;
+#pragma unroll
+        for (int k = 0; k < NW; k++) w[k] = p[(size_t)k * 64];
+        return v;
+    }
+    static __device__ __forceinline__ void st(uint32_t* slab, int slot, int lane, const Proj<C>& v) {
+        const uint32_t* w = reinterpret_cast<const uint32_t*>(&v);
+        uint32_t* p = slab + (size_t)slot * NW * 64 + lane;
+#pragma unroll
+        for (int k = 0; k < NW; k++) p[(size_t)k * 64] = w[k];
+    }
+};
+template <class C, int WAVES = 2>
+__global__ void __launch_bounds__(256, WAVES)
 msm_wave_reduce_kernel(WaveReduceIn<C> in0, WaveReduceIn<C> in1, WaveReduceIn<C> in2, uint32_t blocks_per_input,
                        uint32_t n_inputs, uint32_t segs_per_window, int L, const Aff<C>* __restrict__ salts,
-                       Proj<C>* __restrict__ out) {
+                       Proj<C>* __restrict__ out, uint32_t* __restrict__ slabs) {
     typedef typename C::F F;
+    typedef ReduceSlab<C> SL;
+    enum { RUN = 0, WACC = 1, TMP = 2 };
     extern __shared__ uint32_t lds_raw[];
     const int lane = threadIdx.x & 63;
     Proj<C>* sh = reinterpret_cast<Proj<C>*>(lds_raw) + 64 * (threadIdx.x >> 6);
@@ -1088,7 +1151,11 @@ msm_wave_reduce_kernel(WaveReduceIn<C> in0, WaveReduceIn<C> in1, WaveReduceIn<C>
     }
     const int NS1 = in.mode == 1 ? L : 2 * L - 1;
     const int NST = in.mode == 1 ? L + 6 : NS1 + 18;
-    Proj<C> run = proj_zero<C>(), wacc = proj_zero<C>(), tmp = proj_zero<C>();
+    uint32_t* slab = slabs + (size_t)gb * SL::WORDS;
+    {
+        const Proj<C> z = proj_zero<C>();
+        SL::st(slab, RUN, lane, z); SL::st(slab, WACC, lane, z); SL::st(slab, TMP, lane, z);
+    }
     int step = 0, det = 0, salt_id = 0;
     bool mydet = false, mid_done = false;
     Proj<C>* o = out + ((size_t)which * blocks_per_input + blk) * 3;
@@ -1103,47 +1170,63 @@ msm_wave_reduce_kernel(WaveReduceIn<C> in0, WaveReduceIn<C> in1, WaveReduceIn<C>
         else {
             kind = 4; off = 32 >> (step - NS1 - 12);
             if (!mid_done) {   // between scan and the last tree: publish runW = S_0, drop lane 0 from the tree
-                if (lane == 0) { st_proj<C>(o, run); run = proj_zero<C>(); }
+                if (lane == 0) { st_proj<C>(o, SL::ld(slab, RUN, lane)); SL::st(slab, RUN, lane, proj_zero<C>()); }
                 mid_done = true;
             }
         }
         const bool exch = kind >= 2;
-        if (exch && det == 0) st_proj<C>(sh + lane, kind == 2 ? wacc : run);
-        if (exch) GH_WAVE_SYNC();
-        bool active;
-        Proj<C> q = proj_zero<C>();
-        if (kind == 0) {
-            const uint32_t k = item0 + (uint32_t)lane + 64u * (uint32_t)i;
-            active = k < in.count;
-            if (active) q = ld_proj<C>(in.base + ((size_t)w * in.count + k) * in.stride + in.offset);
-        } else if (kind == 1) {
-            active = true;
-            q = run;
-        } else {
-            const int partner = lane + off;
-            active = kind == 3 ? partner < 64 : lane < off;
-            if (active) q = ld_proj<C>(sh + partner);
-        }
+        if (exch && det == 0) st_proj<C>(sh + lane, SL::ld(slab, kind == 2 ? WACC : RUN, lane));
         if (exch) GH_WAVE_SYNC();
         const bool to_wacc = kind == 1 || kind == 2;
-        Proj<C> p = to_wacc ? wacc : run;
-        if (det > 0) {
-            active = mydet;
-            if (det >= 2) p = tmp;
-            if (det != 2) {
-                Aff<C> s = ld_aff<C>(salts + salt_id);
-                q.x = s.x; q.y = det == 3 ? F::neg(s.y) : s.y; q.z = F::one();
+        const int dst = to_wacc ? WACC : RUN;
+        bool active;
+        if (kind == 0) active = item0 + (uint32_t)lane + 64u * (uint32_t)i < in.count;
+        else if (kind == 1) active = true;
+        else active = kind == 3 ? lane + off < 64 : lane < off;
+        if (det > 0) active = mydet;
+        // the step's second operand (re-loadable: it is read again below for the lanes whose sum is one of the operands)
+        auto load_q = [&]() -> Proj<C> {
+            Proj<C> q = proj_zero<C>();
+            if (det == 1 || det == 3) {
+                const Aff<C> sp = ld_aff<C>(salts + salt_id);
+                q.x = sp.x; q.y = det == 3 ? F::neg(sp.y) : sp.y; q.z = F::one();
+            } else if (kind == 0) {
+                const uint32_t k = item0 + (uint32_t)lane + 64u * (uint32_t)i;
+                if (k < in.count) q = ld_proj<C>(in.base + ((size_t)w * in.count + k) * in.stride + in.offset);
+            } else if (kind == 1) {
+                q = SL::ld(slab, RUN, lane);
+            } else {
+                const int partner = lane + off;
+                if (kind == 3 ? partner < 64 : lane < off) q = ld_proj<C>(sh + partner);
             }
+            return q;
+        };
+        const int src = det >= 2 ? TMP : dst;
+        bool same, pz, qz;
+        Proj<C> r;
+        {
+            const Proj<C> q = load_q();
+            const Proj<C> p = SL::ld(slab, src, lane);
+            r = proj_add_raw<C>(p, q, same, pz, qz);
         }
-        bool same;
-        Proj<C> r = proj_add_sel<C>(p, q, same);
+        if (__any((pz || qz) && active)) {   // p + infinity = p, infinity + q = q: patch those lanes from the operands, read again
+            const Proj<C> q = load_q();
+            const Proj<C> p = SL::ld(slab, src, lane);
+            uint32_t* rw = reinterpret_cast<uint32_t*>(&r);
+            const uint32_t* pw = reinterpret_cast<const uint32_t*>(&p);
+            const uint32_t* qw = reinterpret_cast<const uint32_t*>(&q);
+#pragma unroll
+            for (int k = 0; k < SL::NW; k++) rw[k] = pz ? qw[k] : (qz ? pw[k] : rw[k]);
+        }
+        if (exch) GH_WAVE_SYNC();
         same = same && active;
         if (det == 0) {
             const bool any_same = __any(same) != 0;
-            if (active && !same) { if (to_wacc) wacc = r; else run = r; }
+            if (active && !same) SL::st(slab, dst, lane, r);
             if (any_same) {
                 mydet = same;
                 if (same) {   // salt with x != p.x / p.z  (rare path: out-of-line product)
+                    const Proj<C> p = SL::ld(slab, src, lane);
                     Aff<C> s0 = ld_aff<C>(salts);
                     salt_id = C::FC::eq(C::FC::mul(s0.x, p.z), p.x) ? 1 : 0;
                 }
@@ -1152,19 +1235,16 @@ msm_wave_reduce_kernel(WaveReduceIn<C> in0, WaveReduceIn<C> in1, WaveReduceIn<C>
                 step++;
             }
         } else {
-            if (mydet) {
-                if (det < 3) tmp = r;
-                else if (to_wacc) wacc = r; else run = r;
-            }
+            if (mydet) SL::st(slab, det < 3 ? TMP : dst, lane, r);
             if (det == 3) { det = 0; mydet = false; step++; } else det++;
         }
     }
     if (lane == 0) {
         if (in.mode == 1) {
-            st_proj<C>(o, run);
+            st_proj<C>(o, SL::ld(slab, RUN, lane));
         } else {
-            st_proj<C>(o + 1, wacc);
-            st_proj<C>(o + 2, run);
+            st_proj<C>(o + 1, SL::ld(slab, WACC, lane));
+            st_proj<C>(o + 2, SL::ld(slab, RUN, lane));
         }
     }
 }
