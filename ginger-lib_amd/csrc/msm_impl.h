@@ -765,10 +765,15 @@ struct MsmJob {
                 typedef typename std::conditional<C::F::DEG == 2, F2S<P4, 13>, F3S<P6, 11, GH_F3S_TRIPLE>>::type FS;
                 constexpr int LANES = FS::LANES, TPW = C::F::DEG == 2 ? 32 : 16;
                 const size_t lds_split = 64 * sizeof(P3);
+                uint32_t* slabs = nullptr;
+                char nm[48];
+                snprintf(nm, sizeof nm, "reduce_slabs#%d", slot);
+                int rc = pool_get(nm, (size_t)(nb1 > nb2 ? nb1 : nb2) * P3Slab::WORDS * 4, (void**)&slabs);
+                if (rc) return rc;
                 hipLaunchKernelGGL((msm_wave_reduce_split_kernel<C, FS, LANES, TPW>), dim3(nb1), dim3(64), lds_split, st,
-                                   i0, none, none, nb1, 1u, segs_per_window, L1, (const Aff<C>*)salts, seg_out);
+                                   i0, none, none, nb1, 1u, segs_per_window, L1, (const Aff<C>*)salts, seg_out, slabs);
                 hipLaunchKernelGGL((msm_wave_reduce_split_kernel<C, FS, LANES, TPW>), dim3(nb2), dim3(64), lds_split, st,
-                                   r0, r1, r2, (uint32_t)RW, 3u, 1u, L2, (const Aff<C>*)salts, win_out);
+                                   r0, r1, r2, (uint32_t)RW, 3u, 1u, L2, (const Aff<C>*)salts, win_out, slabs);
                 launched = true;
             }
         }

@@ -1283,11 +1283,52 @@ template <class FS> __device__ __forceinline__ P3 p3_add_sel(const P3& p, const 
     return o;
 }
 
+// without the final operand selects (see proj_add_raw): the caller patches lanes with an infinite operand
+template <class FS> __device__ __forceinline__ P3 p3_add_raw(const P3& p, const P3& q, bool& same, bool& pz, bool& qz) {
+    pz = FS::is_zero(p.z); qz = FS::is_zero(q.z);
+    Fp y1z2 = FS::mul(p.y, q.z);
+    Fp u = FS::sub(FS::mul(p.z, q.y), y1z2);
+    Fp x1z2 = FS::mul(p.x, q.z);
+    Fp v = FS::sub(FS::mul(p.z, q.x), x1z2);
+    Fp z1z2 = FS::mul(p.z, q.z);
+    same = !pz && !qz && FS::is_zero(u) && FS::is_zero(v);
+    Fp vv = FS::sqr(v);
+    Fp r = FS::mul(vv, x1z2);
+    Fp vvv = FS::mul(v, vv);
+    Fp uu = FS::sqr(u);
+    Fp a = FS::sub(FS::sub(FS::mul(uu, z1z2), vvv), FS::dbl(r));
+    P3 o;
+    o.x = FS::mul(v, a);
+    o.z = FS::mul(vvv, z1z2);
+    o.y = FS::sub(FS::mul(FS::sub(r, a), u), FS::mul(vvv, y1z2));
+    return o;
+}
+struct P3Slab {   // run / wacc / tmp of a program, word-major per lane (see ReduceSlab)
+    static constexpr int NW = 3 * NL;
+    static constexpr size_t WORDS = (size_t)3 * NW * 64;
+    static __device__ __forceinline__ P3 ld(const uint32_t* slab, int slot, int lane) {
+        P3 v;
+        uint32_t* w = reinterpret_cast<uint32_t*>(&v);
+        const uint32_t* p = slab + (size_t)slot * NW * 64 + lane;
+#pragma unroll
+        for (int k = 0; k < NW; k++) w[k] = p[(size_t)k * 64];
+        return v;
+    }
+    static __device__ __forceinline__ void st(uint32_t* slab, int slot, int lane, const P3& v) {
+        const uint32_t* w = reinterpret_cast<const uint32_t*>(&v);
+        uint32_t* p = slab + (size_t)slot * NW * 64 + lane;
+#pragma unroll
+        for (int k = 0; k < NW; k++) p[(size_t)k * 64] = w[k];
+    }
+};
+
 template <class C, class FS, int LANES, int TPW>
 __global__ void __launch_bounds__(64, 1)
 msm_wave_reduce_split_kernel(WaveReduceIn<C> in0, WaveReduceIn<C> in1, WaveReduceIn<C> in2, uint32_t blocks_per_input,
                              uint32_t n_inputs, uint32_t segs_per_window, int L, const Aff<C>* __restrict__ salts,
-                             Proj<C>* __restrict__ out) {
+                             Proj<C>* __restrict__ out, uint32_t* __restrict__ slabs) {
+    typedef P3Slab SL;
+    enum { RUN = 0, WACC = 1, TMP = 2 };
     constexpr int LT = TPW == 32 ? 5 : (TPW == 16 ? 4 : 6);
     static_assert((1 << LT) == TPW && TPW * LANES <= 64, "groups per wave");
     extern __shared__ uint32_t lds_raw[];
@@ -1312,7 +1353,11 @@ msm_wave_reduce_split_kernel(WaveReduceIn<C> in0, WaveReduceIn<C> in1, WaveReduc
     }
     const int NS1 = in.mode == 1 ? L : 2 * L - 1;
     const int NST = in.mode == 1 ? L + LT : NS1 + 3 * LT;
-    P3 run = p3_zero<FS>(), wacc = p3_zero<FS>(), tmp = p3_zero<FS>();
+    uint32_t* slab = slabs + (size_t)gb * SL::WORDS;
+    {
+        const P3 z = p3_zero<FS>();
+        SL::st(slab, RUN, lane, z); SL::st(slab, WACC, lane, z); SL::st(slab, TMP, lane, z);
+    }
     int step = 0, det = 0, salt_id = 0;
     bool mydet = false, mid_done = false;
     auto sh_store = [&](const P3& v) {
@@ -1340,51 +1385,66 @@ msm_wave_reduce_split_kernel(WaveReduceIn<C> in0, WaveReduceIn<C> in1, WaveReduc
         else {
             kind = 4; off = (TPW / 2) >> (step - NS1 - 2 * LT);
             if (!mid_done) {   // between scan and the last tree: publish runW = S_0, drop group 0 from the tree
-                if (g == 0) { st_p3(o, run); run = p3_zero<FS>(); }
+                if (g == 0) { st_p3(o, SL::ld(slab, RUN, lane)); SL::st(slab, RUN, lane, p3_zero<FS>()); }
                 mid_done = true;
             }
         }
         const bool exch = kind >= 2;
-        if (exch && det == 0) sh_store(kind == 2 ? wacc : run);
-        if (exch) GH_WAVE_SYNC();
-        bool active;
-        P3 q = p3_zero<FS>();
-        if (kind == 0) {
-            const uint32_t k = item0 + (uint32_t)g + (uint32_t)TPW * (uint32_t)i;
-            active = live && k < in.count;
-            if (active) {
-                const Proj<C>* pt = in.base + ((size_t)w * in.count + k) * in.stride + in.offset;
-                q.x = ld_c(pt, 0); q.y = ld_c(pt, 1); q.z = ld_c(pt, 2);
-            }
-        } else if (kind == 1) {
-            active = live;
-            q = run;
-        } else {
-            active = live && (kind == 3 ? g + off < TPW : g < off);
-            if (active) q = sh_load(lane + off * LANES);
-        }
+        if (exch && det == 0) sh_store(SL::ld(slab, kind == 2 ? WACC : RUN, lane));
         if (exch) GH_WAVE_SYNC();
         const bool to_wacc = kind == 1 || kind == 2;
-        P3 p = to_wacc ? wacc : run;
-        if (det > 0) {
-            active = mydet;
-            if (det >= 2) p = tmp;
-            if (det != 2) {
+        const int dst = to_wacc ? WACC : RUN;
+        bool active;
+        if (kind == 0) active = live && item0 + (uint32_t)g + (uint32_t)TPW * (uint32_t)i < in.count;
+        else if (kind == 1) active = live;
+        else active = live && (kind == 3 ? g + off < TPW : g < off);
+        if (det > 0) active = mydet;
+        auto load_q = [&]() -> P3 {   // the step's second operand; read again below for the lanes whose sum is one of the operands
+            P3 q = p3_zero<FS>();
+            if (det == 1 || det == 3) {
                 q.x = ld_c(salts + salt_id, 0);
                 q.y = ld_c(salts + salt_id, 1);
                 if (det == 3) q.y = FS::neg(q.y);
                 q.z = FS::one();
+            } else if (kind == 0) {
+                const uint32_t k = item0 + (uint32_t)g + (uint32_t)TPW * (uint32_t)i;
+                if (live && k < in.count) {
+                    const Proj<C>* pt = in.base + ((size_t)w * in.count + k) * in.stride + in.offset;
+                    q.x = ld_c(pt, 0); q.y = ld_c(pt, 1); q.z = ld_c(pt, 2);
+                }
+            } else if (kind == 1) {
+                q = SL::ld(slab, RUN, lane);
+            } else {
+                if (live && (kind == 3 ? g + off < TPW : g < off)) q = sh_load(lane + off * LANES);
             }
+            return q;
+        };
+        const int src = det >= 2 ? TMP : dst;
+        bool same, pz, qz;
+        P3 r;
+        {
+            const P3 q = load_q();
+            const P3 p = SL::ld(slab, src, lane);
+            r = p3_add_raw<FS>(p, q, same, pz, qz);
         }
-        bool same;
-        P3 r = p3_add_sel<FS>(p, q, same);
+        if (__any((pz || qz) && active)) {   // p + infinity = p, infinity + q = q
+            const P3 q = load_q();
+            const P3 p = SL::ld(slab, src, lane);
+            uint32_t* rw = reinterpret_cast<uint32_t*>(&r);
+            const uint32_t* pw = reinterpret_cast<const uint32_t*>(&p);
+            const uint32_t* qw = reinterpret_cast<const uint32_t*>(&q);
+#pragma unroll
+            for (int k = 0; k < SL::NW; k++) rw[k] = pz ? qw[k] : (qz ? pw[k] : rw[k]);
+        }
+        if (exch) GH_WAVE_SYNC();
         same = same && active;
         if (det == 0) {
             const bool any_same = __any(same) != 0;
-            if (active && !same) { if (to_wacc) wacc = r; else run = r; }
+            if (active && !same) SL::st(slab, dst, lane, r);
             if (any_same) {
                 mydet = same;
                 // salt with x != p.x / p.z (all lanes run the product: the group shuffles need their partners)
+                const P3 p = SL::ld(slab, src, lane);
                 const bool s0_hits = FS::eq(FS::mul(ld_c(salts, 0), p.z), p.x);
                 if (same) salt_id = s0_hits ? 1 : 0;
                 det = 1;
@@ -1392,19 +1452,16 @@ msm_wave_reduce_split_kernel(WaveReduceIn<C> in0, WaveReduceIn<C> in1, WaveReduc
                 step++;
             }
         } else {
-            if (mydet) {
-                if (det < 3) tmp = r;
-                else if (to_wacc) wacc = r; else run = r;
-            }
+            if (mydet) SL::st(slab, det < 3 ? TMP : dst, lane, r);
             if (det == 3) { det = 0; mydet = false; step++; } else det++;
         }
     }
     if (g == 0) {
         if (in.mode == 1) {
-            st_p3(o, run);
+            st_p3(o, SL::ld(slab, RUN, lane));
         } else {
-            st_p3(o + 1, wacc);
-            st_p3(o + 2, run);
+            st_p3(o + 1, SL::ld(slab, WACC, lane));
+            st_p3(o + 2, SL::ld(slab, RUN, lane));
         }
     }
 }
