@@ -39,6 +39,35 @@ template <class P> __device__ __forceinline__ Fp fp_mul_2c(const Fp& a, const Fp
     return r;
 }
 
+// add / sub with the carry rippling through 13 packed 58-bit pairs instead of 26 limbs (half the dependent chain)
+template <class P> __device__ __forceinline__ Fp fp_add_packed(const Fp& a, const Fp& b) {
+    uint64_t t[NL / 2];
+    uint64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < NL / 2; i++) {
+        const uint64_t x = ((uint64_t)a.l[2 * i] | ((uint64_t)a.l[2 * i + 1] << LB)) + ((uint64_t)b.l[2 * i] | ((uint64_t)b.l[2 * i + 1] << LB)) + c;
+        t[i] = x & ((1ull << (2 * LB)) - 1);
+        c = x >> (2 * LB);
+    }
+    // t - p with borrow, select
+    uint64_t d[NL / 2];
+    int64_t bw = 0;
+#pragma unroll
+    for (int i = 0; i < NL / 2; i++) {
+        const int64_t x = (int64_t)t[i] - (int64_t)((uint64_t)P::P[2 * i] | ((uint64_t)P::P[2 * i + 1] << LB)) + bw;
+        d[i] = (uint64_t)x & ((1ull << (2 * LB)) - 1);
+        bw = x >> 63;
+    }
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < NL / 2; i++) {
+        const uint64_t v = bw ? t[i] : d[i];
+        r.l[2 * i] = (uint32_t)v & LM;
+        r.l[2 * i + 1] = (uint32_t)(v >> LB);
+    }
+    return r;
+}
+
 template <int KIND> __global__ void __launch_bounds__(64) chain_kernel(uint32_t* io, int iters) {
     Fp x, y, z, w;
     const uint32_t t = blockIdx.x * 64 + threadIdx.x;
@@ -54,6 +83,8 @@ template <int KIND> __global__ void __launch_bounds__(64) chain_kernel(uint32_t*
         if (KIND == 2) { x = fp_add<P4>(x, y); x = fp_sub<P4>(x, z); x = fp_add<P4>(x, w); x = fp_sub<P4>(x, y); }   // serial carry chains only
         if (KIND == 3) { Fp t = fp_mul2<P4>(x, y, z, w); t = fp_sub<P4>(t, y); t = fp_add<P4>(t, z); w = z; z = y; y = x; x = t; }       // the rounds' mix
         if (KIND == 4) { x = fp_mul_small<P4, 13>(x); }
+        if (KIND == 8) { x = fp_add_packed<P4>(x, y); x = fp_add_packed<P4>(x, z); x = fp_add_packed<P4>(x, w); x = fp_add_packed<P4>(x, y); }
+        if (KIND == 9) { x = fp_add<P4>(x, y); x = fp_add<P4>(x, z); x = fp_add<P4>(x, w); x = fp_add<P4>(x, y); }
         if (KIND == 5) { x = fp_mul<P4>(x, y); z = fp_mul<P4>(z, w); }                         // two independent products
     }
     for (int i = 0; i < NL; i++) io[(size_t)t * NL + i + 64] = x.l[i] ^ z.l[i];
@@ -93,5 +124,7 @@ int main() {
     run<2>("add, sub, add, sub (carry chains)", d, 4000, cus);
     run<3>("fp_mul2 + sub + add", d, 1500, cus);
     run<4>("fp_mul_small<13>", d, 4000, cus);
+    run<9>("4 x fp_add", d, 4000, cus);
+    run<8>("4 x fp_add, carries through 13 packed pairs", d, 4000, cus);
     return 0;
 }
