@@ -4,6 +4,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import pyref
+import support as S
 from __graft_entry__ import _load_pkg
 gl = _load_pkg()
 what, log_n = sys.argv[1], int(sys.argv[2])
@@ -22,8 +23,7 @@ if what == "msm":
     for i, Q in enumerate(pts):
         b[i, :12] = pyref.fe_to_abi(C.F, Q[0][0]); b[i, 12:] = pyref.fe_to_abi(C.F, Q[1][0])
     bases = np.tile(b, (max(1, n // 1024), 1))[:n]
-    s = rng.integers(0, 1 << 64, size=(n, 12), dtype=np.uint64)
-    s[:, 11] &= np.uint64((1 << 40) - 1)
+    s = S.random_scalars_np(n, seed=11, below=C.order)        # uniform below r, the reference's sampling shape (fields/macros.rs:11-28)
     rb = gl.ResidentBases("mnt4753_g1", bases)
     if len(sys.argv) > 4 and sys.argv[4] == "table":
         print("shift table window", rb.precompute(0), flush=True)
@@ -32,8 +32,7 @@ if what == "msm":
         t0 = time.time(); rb.msm_dev(ds, n)
         print("msm log_n", log_n, "wall %.2f ms" % ((time.time() - t0) * 1e3), gl.msm_last_timing(), flush=True)
 else:
-    a = rng.integers(0, 1 << 64, size=(n, 12), dtype=np.uint64)
-    a[:, 11] &= np.uint64((1 << 40) - 1)
+    a = S.random_scalars_np(n, seed=12, below=pyref.P6.p)     # field elements of MNT4-753 Fr
     buf = gl.DeviceBuffer(n * 96).upload(a)
     dom = gl.EvaluationDomain("mnt4753_fr", n)
     for r in range(reps):
