@@ -257,11 +257,20 @@ class ResidentProvingKey:
         aux_used = aux[:n_var - len(inp)]
         pad = np.zeros((n_var - len(inp) - len(aux_used), 12), dtype=np.uint64)
         # scalars  input || aux || 1 || 1 || r   and the same with s; the aux part alone is the l_query's vector
-        sc_r = np.concatenate([inp, aux_used, pad, one, one, r])
-        d_r = gl.DeviceBuffer(sc_r.nbytes).upload(sc_r)
-        d_s = gl.DeviceBuffer(sc_r.nbytes)
+        # (uploaded piecewise: concatenating two 100 MB host vectors first costs more than the MSM stage's sort)
+        import ctypes
         lib = gl.load_library()
-        gl._check(lib.gh_dev_upload(d_s.ptr, gl._ptr(np.concatenate([inp, aux_used, pad, one, one, s])), sc_r.nbytes))
+        rows_total = n_var + 3
+        d_r = gl.DeviceBuffer(rows_total * 96)
+        d_s = gl.DeviceBuffer(rows_total * 96)
+        for buf, last in ((d_r, r), (d_s, s)):
+            row = 0
+            for part in (inp, aux_used, pad, np.concatenate([one, one, last])):
+                if len(part):
+                    part = np.ascontiguousarray(part, dtype=np.uint64)
+                    gl._check(lib.gh_dev_upload(ctypes.c_void_p(buf.ptr.value + row * 96), gl._ptr(part), part.nbytes))
+                    row += len(part)
+            assert row == rows_total
 
         class _View:                          # aux_assignment inside d_r
             def __init__(self, buf, row0):
