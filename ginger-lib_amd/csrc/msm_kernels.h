@@ -1002,9 +1002,9 @@ msm_heavy_combine_kernel(const Proj<C>* __restrict__ partials, const uint32_t* _
 // msm_wave_reduce_kernel is a "wave program": one wave per segment of 64 * L consecutive items of
 // one window; lane l owns items l, l + 64, l + 128, ... (stride 64).  Every step of the program is
 // one projective addition issued from a SINGLE inlined call site (operands are selected per
-// step), so the kernel stays within 256 VGPRs / 2 waves per SIMD and passes nothing through
-// scratch (the earlier call-based version moved ~7 KB of scratch per addition and was
-// scratch-bandwidth bound):
+// step; the earlier call-based version moved ~7 KB of scratch per addition and was
+// scratch-bandwidth bound).  The program's accumulators are parked in a global slab between steps
+// (ReduceSlab below):
 //   steps 0 .. 2L-2   serial:  run += item_i  (i = L-1 .. 0),  wacc += run      -> run_l = sum_i x,
 //                                                                                   wacc_l = sum_i i * x
 //   6 steps           tree over lanes of wacc                    -> A  = sum_l wacc_l
@@ -1055,8 +1055,8 @@ template <class C> __device__ __forceinline__ Proj<C> proj_add_sel(const Proj<C>
 
 // A block may carry blockDim.x / 64 INDEPENDENT waves (each its own program and LDS region, so the
 // exchanges need wave-level ordering only, no s_barrier).  Measured at 2^20 buckets: 1, 2, 3 or 4
-// waves per block, with or without a block barrier per step, all take the same 5.2 ms for level 1
-// (104 us per step with every SIMD occupied, 55 us on an otherwise idle chip) -- the default is 1.
+// waves per block, with or without a block barrier per step, all take the same time for level 1
+// -- the default is 1.
 #define GH_WAVE_SYNC()                                           \
     do {                                                         \
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   \
