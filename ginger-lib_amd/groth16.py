@@ -133,24 +133,32 @@ class ResidentProvingKey:
     The reference issues nine MSMs because the input and aux assignments are separate vectors and adds
     r * delta, the [0] entries and alpha / beta by hand (prover.rs:273-316).  The sums are the same group
     elements when each query is ONE resident vector
-        a_query[1..] || a_query[0] || alpha_g1 || delta_g1        with scalars  input || aux || 1 || 1 || r
-    (likewise b_g1 / b_g2 with beta and s, and h_query as a whole), so a proof needs five MSMs -- four on G1,
-    issued as one pipelined batch, one on G2 -- and no 2-pair MSM pays the latency of a full bucket reduction."""
+        a_query[1..] || a_query[0] || alpha_g1 || delta_g1 || infinity     with scalars  input || aux || 1 || 1 || r || s
+        b_query[1..] || b_query[0] || beta     || infinity || delta         with the SAME scalar vector
+    (the infinity base swallows the other query's blinding scalar; h_query as a whole), so a proof needs five MSMs
+    -- four on G1, issued as one pipelined batch, one on G2 --, ONE upload of the assignment, and no 2-pair MSM pays
+    the latency of a full bucket reduction."""
 
     def __init__(self, gl, pairing, pk, num_inputs, precompute=True):
         assert pairing in ("mnt4753", "mnt6753")
         self.gl, self.pk, self.num_inputs = gl, pk, int(num_inputs)
         self.g1, self.g2 = pairing + "_g1", pairing + "_g2"
         row = lambda v: np.asarray(v, dtype=np.uint64).reshape(1, -1)
-        ext = lambda q, c, d: np.ascontiguousarray(np.concatenate([pk[q][1:], row(pk[q][0]), row(pk[c]), row(pk[d])]), dtype=np.uint64)
-        vectors = {"a": (self.g1, ext("a_query", "alpha_g1", "delta_g1")),
-                   "b1": (self.g1, ext("b_g1_query", "beta_g1", "delta_g1")),
-                   "b2": (self.g2, ext("b_g2_query", "beta_g2", "delta_g2")),
-                   "h": (self.g1, np.ascontiguousarray(pk["h_query"], dtype=np.uint64)),
-                   "l": (self.g1, np.ascontiguousarray(pk["l_query"], dtype=np.uint64))}
+        def ext(q, c, d, delta_last):       # q[1..] || q[0] || c || (delta, infinity) or (infinity, delta)
+            dl = row(pk[d])
+            tail = [np.zeros_like(dl), dl] if delta_last else [dl, np.zeros_like(dl)]
+            rows = np.ascontiguousarray(np.concatenate([pk[q][1:], row(pk[q][0]), row(pk[c])] + tail), dtype=np.uint64)
+            inf = np.zeros(len(rows), dtype=np.uint8)
+            inf[-2 if delta_last else -1] = 1
+            return rows, inf
+        vectors = {"a": (self.g1,) + ext("a_query", "alpha_g1", "delta_g1", False),
+                   "b1": (self.g1,) + ext("b_g1_query", "beta_g1", "delta_g1", True),
+                   "b2": (self.g2,) + ext("b_g2_query", "beta_g2", "delta_g2", True),
+                   "h": (self.g1, np.ascontiguousarray(pk["h_query"], dtype=np.uint64), None),
+                   "l": (self.g1, np.ascontiguousarray(pk["l_query"], dtype=np.uint64), None)}
         self.keys = {}
-        for name, (curve, rows) in vectors.items():
-            rb = gl.ResidentBases(curve, rows)
+        for name, (curve, rows, inf) in vectors.items():
+            rb = gl.ResidentBases(curve, rows, infinity=inf)
             if precompute and rb.n:
                 try:
                     rb.precompute(0)
@@ -170,10 +178,13 @@ class ResidentProvingKey:
         self.pk = pk
         self.pairing = pairing
         r1, r2 = 2 * _FQ_BYTES + 1, 2 * _FQ_BYTES * _G2_DEG[pairing] + 1
-        ext = lambda q, c, d, rec: pk[q][rec:] + pk[q][:rec] + pk[c] + pk[d]          # q[1..] || q[0] || c || d
-        vectors = {"a": (self.g1, ext("a_query", "alpha_g1", "delta_g1", r1)),
-                   "b1": (self.g1, ext("b_g1_query", "beta_g1", "delta_g1", r1)),
-                   "b2": (self.g2, ext("b_g2_query", "beta_g2", "delta_g2", r2)),
+        def ext(q, c, d, rec, delta_last):  # q[1..] || q[0] || c || (delta, infinity) or (infinity, delta), GroupAffine::write records
+            zero = bytes(rec - 1) + b"\x01"                                             # an infinity record: flag byte set
+            tail = zero + pk[d] if delta_last else pk[d] + zero
+            return pk[q][rec:] + pk[q][:rec] + pk[c] + tail
+        vectors = {"a": (self.g1, ext("a_query", "alpha_g1", "delta_g1", r1, False)),
+                   "b1": (self.g1, ext("b_g1_query", "beta_g1", "delta_g1", r1, True)),
+                   "b2": (self.g2, ext("b_g2_query", "beta_g2", "delta_g2", r2, True)),
                    "h": (self.g1, pk["h_query"]), "l": (self.g1, pk["l_query"])}
         self.keys = {}
         for name, (curve, data) in vectors.items():
@@ -252,25 +263,25 @@ class ResidentProvingKey:
         one[0, 0] = 1
         # the variable part must line up with the query: len(a_query) - 1 scalars (a real key has exactly
         # len(input) + len(aux) of them; a longer aux vector is cut where the reference's zip cuts it, :36)
-        n_var = self.keys["a"].n - 3
-        assert self.keys["b1"].n - 3 == n_var and self.keys["b2"].n - 3 == n_var and n_var >= len(inp)
+        n_var = self.keys["a"].n - 4
+        assert self.keys["b1"].n - 4 == n_var and self.keys["b2"].n - 4 == n_var and n_var >= len(inp)
         aux_used = aux[:n_var - len(inp)]
         pad = np.zeros((n_var - len(inp) - len(aux_used), 12), dtype=np.uint64)
-        # scalars  input || aux || 1 || 1 || r   and the same with s; the aux part alone is the l_query's vector
-        # (uploaded piecewise: concatenating two 100 MB host vectors first costs more than the MSM stage's sort)
+        # ONE scalar vector  input || aux || 1 || 1 || r || s  for the a, b_g1 and b_g2 queries (each key pairs the blinding scalar
+        # it does not use with an infinity base); the aux part alone is the l_query's vector.
+        # (uploaded piecewise: concatenating 100 MB host vectors first costs more than the MSM stage's sort)
         import ctypes
         lib = gl.load_library()
-        rows_total = n_var + 3
+        rows_total = n_var + 4
         d_r = gl.DeviceBuffer(rows_total * 96)
-        d_s = gl.DeviceBuffer(rows_total * 96)
-        for buf, last in ((d_r, r), (d_s, s)):
-            row = 0
-            for part in (inp, aux_used, pad, np.concatenate([one, one, last])):
-                if len(part):
-                    part = np.ascontiguousarray(part, dtype=np.uint64)
-                    gl._check(lib.gh_dev_upload(ctypes.c_void_p(buf.ptr.value + row * 96), gl._ptr(part), part.nbytes))
-                    row += len(part)
-            assert row == rows_total
+        row = 0
+        for part in (inp, aux_used, pad, np.concatenate([one, one, r, s])):
+            if len(part):
+                part = np.ascontiguousarray(part, dtype=np.uint64)
+                gl._check(lib.gh_dev_upload(ctypes.c_void_p(d_r.ptr.value + row * 96), gl._ptr(part), part.nbytes))
+                row += len(part)
+        assert row == rows_total
+        d_s = d_r
 
         class _View:                          # aux_assignment inside d_r
             def __init__(self, buf, row0):
@@ -288,10 +299,9 @@ class ResidentProvingKey:
         d_l = gl.DeviceBuffer(max(96, aux.nbytes)).upload(aux) if own_l else _View(d_r, ni - 1)
         k = self.keys
         g_a, g1_b, h_acc, l_acc = gl.msm_batch_dev([
-            (k["a"], d_r, n_var + 3), (k["b1"], d_s, n_var + 3), (k["h"], d_h, n_h), (k["l"], d_l, len(aux))])
-        g2_b = k["b2"].msm_dev(d_s, n_var + 3)
+            (k["a"], d_r, n_var + 4), (k["b1"], d_s, n_var + 4), (k["h"], d_h, n_h), (k["l"], d_l, len(aux))])
+        g2_b = k["b2"].msm_dev(d_s, n_var + 4)
         d_r.free()
-        d_s.free()
         if own_l:
             d_l.free()
         if own_h:
