@@ -42,8 +42,8 @@ FPMUL_PEAK_PER_S = 23.4e9       # measured 753-bit Montgomery products/s, profil
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--log-n", type=int, default=20, help="log2 of MSM pairs per GPU")
     ap.add_argument("--ntt-log-n", type=int, default=24)
     ap.add_argument("--window", type=int, default=0, help="MSM window override (0 = auto)")
