@@ -127,4 +127,42 @@ template <class C> GH_HD_NOINLINE Proj<C> proj_madd_call(const Proj<C>& p, const
 
 template <class C> GH_HD Aff<C> aff_neg(const Aff<C>& q) { return Aff<C>{q.x, C::F::neg(q.y)}; }
 
+// ----- extended Jacobian ("XYZZ") bucket accumulators:  x = X / ZZ,  y = Y / ZZZ,  ZZ^3 = ZZZ^2,  infinity <=> ZZ == 0.
+// The reference's bucket update is add_assign_mixed (madd-1998-cmo, swp.rs:481-519: 9 M + 2 S on (X : Y : Z)).  A bucket sum
+// is only ever read through its affine image, so the accumulator is free to use the cheaper mixed addition
+// madd-2008-s (8 M + 2 S, no curve coefficient), and Y3 = R (Q - X3) - Y1 PPP is ONE dual product (fp_mul2s):
+// 10 multiplications / 9 reductions per bucket update instead of 11 / 11.  xyzz_to_proj() hands the sum to the
+// projective bucket reduction (3 M per bucket, once).
+template <class C> struct Xyzz {
+    typename C::F::T x, y, zz, zzz;
+};
+template <class C> GH_HD Xyzz<C> xyzz_zero() {
+    typedef typename C::F F;
+    return Xyzz<C>{F::zero(), F::one(), F::zero(), F::zero()};
+}
+template <class C> GH_HD bool xyzz_is_zero(const Xyzz<C>& p) { return C::F::is_zero(p.zz); }
+// p += q for q affine, not infinity, and q != +-p unless p is infinity (P == Q is the caller's business: `same` reports it and
+// p is returned unchanged; P == -Q needs no case: PP = 0 makes ZZ3 = ZZZ3 = 0)
+template <class C, class F = typename C::F> GH_HD Xyzz<C> xyzz_madd(const Xyzz<C>& p, const Aff<C>& q, bool& same) {
+    same = false;
+    if (xyzz_is_zero(p)) return Xyzz<C>{q.x, q.y, F::one(), F::one()};
+    typename F::T pp = F::sub(F::mul(q.x, p.zz), p.x);         // P = U2 - X1
+    typename F::T r = F::sub(F::mul(q.y, p.zzz), p.y);         // R = S2 - Y1
+    if (F::is_zero(pp) && F::is_zero(r)) { same = true; return p; }
+    typename F::T p2 = F::sqr(pp);
+    typename F::T p3 = F::mul(pp, p2);
+    typename F::T qq = F::mul(p.x, p2);
+    Xyzz<C> o;
+    o.x = F::sub(F::sub(F::sqr(r), p3), F::dbl(qq));
+    o.y = F::mul_sub_mul(r, F::sub(qq, o.x), p.y, p3);
+    o.zz = F::mul(p.zz, p2);
+    o.zzz = F::mul(p.zzz, p3);
+    return o;
+}
+// (X : Y : ZZ : ZZZ) -> homogeneous (X ZZZ : Y ZZ : ZZ ZZZ); infinity -> (0, 1, 0)
+template <class C, class F = typename C::F> GH_HD Proj<C> xyzz_to_proj(const Xyzz<C>& p) {
+    if (xyzz_is_zero(p)) return proj_zero<C>();
+    return Proj<C>{F::mul(p.x, p.zzz), F::mul(p.y, p.zz), F::mul(p.zz, p.zzz)};
+}
+
 }  // namespace gh

@@ -572,7 +572,20 @@ struct MsmJob {
                                        (const uint32_t*)chunk_start, n_heavy, n_chunks, heavy_chunk, partials);
                 }
             }
-            if (!(is_g2 && !no_split)) {
+            // G1: XYZZ accumulators (msm_kernels.h 4a: 10 multiplications / 9 reductions per update); GH_ACC_XYZZ=0 selects the
+            // homogeneous-projective kernel (madd-1998-cmo, 11 / 11) for A/B measurements
+            static const bool acc_xyzz = !(getenv("GH_ACC_XYZZ") && atoi(getenv("GH_ACC_XYZZ")) == 0);
+            bool done_xyzz = false;
+            if constexpr (C::F::DEG == 1) {
+                if (acc_xyzz && acc_waves >= 2) {
+                    hipLaunchKernelGGL((msm_accumulate_xyzz_kernel<C>), dim3((unsigned)((tasks + 255) / 256)), dim3(256), 0, st,
+                                       (const Aff<C>*)src_points, (const uint32_t*)sorted, (const uint32_t*)starts,
+                                       (const uint32_t*)counts, (const uint32_t*)order, (uint32_t)total, (const Aff<C>*)salts, buckets,
+                                       (const uint32_t*)chunk_start, n_heavy, n_chunks, heavy_chunk, partials, 0u, 0u);
+                    done_xyzz = true;
+                }
+            }
+            if (!(is_g2 && !no_split) && !done_xyzz) {
                 if (acc_waves >= 2)
                     hipLaunchKernelGGL((msm_accumulate_kernel<C, 2>), dim3((unsigned)((tasks + 255) / 256)), dim3(256), 0, st,
                                        (const Aff<C>*)src_points, (const uint32_t*)sorted, (const uint32_t*)starts,
@@ -731,7 +744,7 @@ struct MsmJob {
             const uint32_t* stR = aff_st + (size_t)(R - 1) * stride;
             const uint32_t* mR = aff_cnt + (size_t)(R - 1) * stride;
             if constexpr (C::F::DEG == 1) {
-                hipLaunchKernelGGL((msm_accumulate_kernel<C, 2, true>), dim3((nbk + 255) / 256), dim3(256), 0, st, (const Aff<C>*)in,
+                hipLaunchKernelGGL((msm_accumulate_xyzz_kernel<C, true>), dim3((nbk + 255) / 256), dim3(256), 0, st, (const Aff<C>*)in,
                                    (const uint32_t*)nullptr, stR, mR, (const uint32_t*)nullptr, nbk, (const Aff<C>*)salts, buckets,
                                    (const uint32_t*)nullptr, 0u, 0u, heavy_chunk, (Proj<C>*)nullptr, bq[j], T(j, R));
             } else {

@@ -651,6 +651,127 @@ msm_accumulate_kernel(const Aff<C>* __restrict__ bases, const uint32_t* __restri
     st_proj<C>(dst, acc);
 }
 
+// ---------------------------------------------------------------- 4a. G1 bucket accumulation on XYZZ accumulators
+// The same task list, the same list walk and the same salt detour as msm_accumulate_kernel, with the running sum in
+// extended Jacobian coordinates (ec29.h, Xyzz): madd-2008-s, 8 M + 2 S, and Y3 as one dual product on a single
+// accumulator chain (fp_mul2s) -- 12 194 v_mad_u64_u32 per bucket update where madd-1998-cmo issues 14 226.
+// Register plan (256 VGPRs, two waves per SIMD): ZZ and ZZZ stay in registers; X and Y of the running sum live in LDS
+// (word-major, 2 x 26 KiB per block) and are read where the formula needs them (X: P and Q; Y: R and Y3), so the loop
+// never holds more than six field elements next to a product's own m / r arrays.
+// Output: the projective image (X ZZZ : Y ZZ : ZZ ZZZ) the bucket reduction expects.
+template <class C, bool AFFIN = false>
+__global__ void __launch_bounds__(256, 2)
+msm_accumulate_xyzz_kernel(const Aff<C>* __restrict__ bases, const uint32_t* __restrict__ sorted,
+                           const uint32_t* __restrict__ starts, const uint32_t* __restrict__ counts,
+                           const uint32_t* __restrict__ order, uint32_t total,
+                           const Aff<C>* __restrict__ salts, Proj<C>* __restrict__ buckets,
+                           const uint32_t* __restrict__ chunk_start, uint32_t n_heavy, uint32_t n_chunks, uint32_t chunk,
+                           Proj<C>* __restrict__ partials, uint32_t g_first = 0, uint32_t list_base = 0) {
+    typedef typename C::PF P;
+    static_assert(C::F::DEG == 1, "XYZZ accumulation kernel: prime-field curves");
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_chunks + (total - n_heavy)) return;
+    uint32_t beg, cnt;
+    Proj<C>* dst;
+    if constexpr (AFFIN) {
+        const uint32_t g = g_first + t;
+        beg = starts[g] - list_base; cnt = counts[g];
+        dst = buckets + g;
+    } else if (t >= n_chunks) {
+        const uint32_t g = order[n_heavy + (t - n_chunks)];
+        beg = starts[g]; cnt = counts[g];
+        dst = buckets + g;
+    } else {
+        uint32_t lo = 0, hi = n_heavy;   // largest h with chunk_start[h] <= t
+        while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (chunk_start[mid] <= t) lo = mid; else hi = mid; }
+        const uint32_t g = order[lo], j = t - chunk_start[lo];
+        beg = starts[g] + j * chunk;
+        cnt = counts[g] - j * chunk;
+        if (cnt > chunk) cnt = chunk;
+        dst = partials + t;
+    }
+    __shared__ uint32_t park[2][NL][256];     // [0]: X, [1]: Y of this thread's running sum
+    auto put = [&](int s, const Fp& v) {
+#pragma unroll
+        for (int w = 0; w < NL; w++) park[s][w][threadIdx.x] = v.l[w];
+    };
+    auto get = [&](int s) {
+        Fp v;
+#pragma unroll
+        for (int w = 0; w < NL; w++) v.l[w] = park[s][w][threadIdx.x];
+        return v;
+    };
+#define GH_FENCE() __builtin_amdgcn_sched_barrier(0)
+    Fp zz = fp_zero(), zzz = fp_zero();
+    uint32_t k = 0;
+    int phase = 0, salt_id = 0;     // phase 0: list entry k; 1: +S; 2: entry k again; 3: -S
+    uint32_t guard = 0;
+    while (k < cnt && guard < 4 * cnt + 8) {
+        guard++;
+        Fp qx, qy;
+        if (phase == 1 || phase == 3) {
+            const Aff<C> s = ld_aff<C>(salts + salt_id);
+            qx = s.x; qy = phase == 3 ? fp_neg<P>(s.y) : s.y;
+        } else {
+            if constexpr (AFFIN) {
+                const uint32_t e = beg + k;
+                qx = t64_ld_x(bases, e >> 6, e & 63u);
+                qy = t64_ld_y(bases, e >> 6, e & 63u);
+                if (phase == 0 && qx.l[0] == AFF_MARK) { k++; continue; }   // a cancelled pair: nothing to add
+            } else {
+                const uint32_t e = sorted[beg + k];
+                const Aff<C> b = ld_aff<C>(bases + (e & 0x7FFFFFFFu));
+                qx = b.x; qy = (e >> 31) ? fp_neg<P>(b.y) : b.y;
+            }
+        }
+        if (fp_is_zero(zz)) {
+            put(0, qx); put(1, qy);
+            zz = fp_one<P>(); zzz = zz;
+        } else {
+            Fp pp = fp_mul<P>(qx, zz);                              // U2
+            GH_FENCE();
+            Fp r = fp_mul<P>(qy, zzz);                              // S2
+            GH_FENCE();
+            pp = fp_sub<P>(pp, get(0));                             // P = U2 - X1
+            r = fp_sub<P>(r, get(1));                               // R = S2 - Y1
+            if (phase == 0 && fp_is_zero(pp) && fp_is_zero(r)) {    // acc == q: the detour (swp.rs:492-495 doubles here)
+                salt_id = fp_eq(qx, ld_aff<C>(salts).x) ? 1 : 0;
+                phase = 1;
+                continue;
+            }
+            GH_FENCE();
+            Fp p2 = fp_sqr<P>(pp);                                  // PP
+            GH_FENCE();
+            zz = fp_mul<P>(zz, p2);                                 // ZZ3
+            GH_FENCE();
+            pp = fp_mul<P>(pp, p2);                                 // PPP
+            GH_FENCE();
+            zzz = fp_mul<P>(zzz, pp);                               // ZZZ3
+            GH_FENCE();
+            p2 = fp_mul<P>(get(0), p2);                             // Q = X1 PP
+            GH_FENCE();
+            Fp x3 = fp_sub<P>(fp_sub<P>(fp_sqr<P>(r), pp), fp_dbl<P>(p2));
+            put(0, x3);
+            GH_FENCE();
+            p2 = fp_sub<P>(p2, x3);                                 // Q - X3
+            GH_FENCE();
+            const Fp ny = fp_neg<P>(get(1));
+            GH_FENCE();
+            put(1, fp_mul2s<P>(r, p2, ny, pp));                     // Y3 = R (Q - X3) - Y1 PPP
+            GH_FENCE();
+        }
+        if (phase == 0 || phase == 3) { k++; phase = 0; } else phase++;
+    }
+#undef GH_FENCE
+    Proj<C> out = proj_zero<C>();
+    if (!fp_is_zero(zz)) {
+        out.x = fp_mul<P>(get(0), zzz);
+        out.y = fp_mul<P>(get(1), zz);
+        out.z = fp_mul<P>(zz, zzz);
+    }
+    st_proj<C>(dst, out);
+}
+
 // ---------------------------------------------------------------- 4b. G2 over Fq2: lane-pair formulation
 // An Fq2 element (c0, c1) lives in TWO adjacent lanes: c0 in the even lane, c1 in the odd one, so a
 // G2 point costs each lane the registers of a G1 point and the kernel needs neither out-of-line

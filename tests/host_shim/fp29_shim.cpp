@@ -86,6 +86,23 @@ template <class HC> static void h64_ec(int op, const uint64_t* p, const uint64_t
 template <class P> static void fp_mul2_op(const uint32_t* a, const uint32_t* b, const uint32_t* c, const uint32_t* d, uint32_t* out) {
     fp_pack(out, fp_mul2<P>(fp_unpack(a), fp_unpack(b), fp_unpack(c), fp_unpack(d)));
 }
+template <class P> static void fp_mul2s_op(const uint32_t* a, const uint32_t* b, const uint32_t* c, const uint32_t* d, uint32_t* out) {
+    fp_pack(out, fp_mul2s<P>(fp_unpack(a), fp_unpack(b), fp_unpack(c), fp_unpack(d)));
+}
+// XYZZ mixed addition (ec29.h): p = (X, Y, ZZ, ZZZ) and q = (x, y) in ABI Montgomery words; out = the sum's four coordinates
+// followed by its projective image (xyzz_to_proj); returns the `same` flag
+template <class C> static int xyzz_op(const uint32_t* p, const uint32_t* q, uint32_t* out) {
+    typedef typename C::F F;
+    const int W = 24 * F::DEG;
+    Xyzz<C> a{F::from_abi(p), F::from_abi(p + W), F::from_abi(p + 2 * W), F::from_abi(p + 3 * W)};
+    Aff<C> b{F::from_abi(q), F::from_abi(q + W)};
+    bool same = false;
+    const Xyzz<C> r = xyzz_madd<C>(a, b, same);
+    F::to_abi(out, r.x); F::to_abi(out + W, r.y); F::to_abi(out + 2 * W, r.zz); F::to_abi(out + 3 * W, r.zzz);
+    const Proj<C> h = xyzz_to_proj<C>(r);
+    F::to_abi(out + 4 * W, h.x); F::to_abi(out + 5 * W, h.y); F::to_abi(out + 6 * W, h.z);
+    return same ? 1 : 0;
+}
 template <class P> static void fp_mul3_op(const uint32_t* a, const uint32_t* b, const uint32_t* c, const uint32_t* d, const uint32_t* e,
                                            const uint32_t* f, uint32_t* out) {
     fp_pack(out, fp_mul3<P>(fp_unpack(a), fp_unpack(b), fp_unpack(c), fp_unpack(d), fp_unpack(e), fp_unpack(f)));
@@ -94,6 +111,18 @@ extern "C" {
 void t_fp_mul3(int field, const uint32_t* a, const uint32_t* b, const uint32_t* c, const uint32_t* d, const uint32_t* e,
                const uint32_t* f, uint32_t* out) {
     if (field == 4) fp_mul3_op<P4>(a, b, c, d, e, f, out); else fp_mul3_op<P6>(a, b, c, d, e, f, out);
+}
+void t_fp_mul2s(int field, const uint32_t* a, const uint32_t* b, const uint32_t* c, const uint32_t* d, uint32_t* out) {
+    if (field == 4) fp_mul2s_op<P4>(a, b, c, d, out); else fp_mul2s_op<P6>(a, b, c, d, out);
+}
+int t_xyzz_madd(int curve, const uint32_t* p, const uint32_t* q, uint32_t* out) {
+    switch (curve) {
+        case 0: return xyzz_op<Mnt4G1>(p, q, out);
+        case 1: return xyzz_op<Mnt4G2>(p, q, out);
+        case 2: return xyzz_op<Mnt6G1>(p, q, out);
+        case 3: return xyzz_op<Mnt6G2>(p, q, out);
+    }
+    return -1;
 }
 void t_fp_mul2(int field, const uint32_t* a, const uint32_t* b, const uint32_t* c, const uint32_t* d, uint32_t* out) {
     if (field == 4) fp_mul2_op<P4>(a, b, c, d, out); else fp_mul2_op<P6>(a, b, c, d, out);

@@ -157,6 +157,84 @@ def test_curve_ops(shim, cid, name):
     assert result(out) is None
 
 
+@pytest.mark.parametrize("fid,F", [(4, pyref.P4), (6, pyref.P6)])
+def test_dual_product_single_accumulator(shim, fid, F):
+    """fp_mul2s: (a b + c d) 2^-754 on ONE 64-bit accumulator chain.  Its columns stay below 2^64 only because all operands are
+    fully reduced; the operands with every limb at its maximum (2^29 - 1, top limb p_25 - 1: still below p) come closest."""
+    p = F.p
+    RIinv = pow(pow(2, 754, p), -1, p)
+    top = p >> 725
+    ones = sum(((1 << 29) - 1) << (29 * i) for i in range(25)) | ((top - 1) << 725)
+    assert ones < p
+    rng = pyref.Rng(90 + fid)
+    out = (U * 24)()
+    cases = [(ones, ones, ones, ones), (p - 1, p - 1, p - 1, p - 1), (ones, p - 1, p - 1, ones), (0, 0, 0, 0), (1, p - 1, p - 1, 1), (ones, 0, 0, ones)]
+    cases += [tuple(rng.field_elem(p) for _ in range(4)) for _ in range(300)]
+    # operands that drive the m digits high as well: a b + c d = -1 * 2^(29 k) patterns are not constructible directly; random
+    # values with saturated low limbs cover the carry paths
+    for _ in range(100):
+        a, b, c, d = (rng.field_elem(p) | ((1 << 290) - 1) for _ in range(4))
+        cases.append((a % p, b % p, c % p, d % p))
+    for a, b, c, d in cases:
+        shim.t_fp_mul2s(fid, words(a), words(b), words(c), words(d), out)
+        assert toint(out) == ((a * b + c * d) * RIinv) % p
+
+
+@pytest.mark.parametrize("cid,name", list(enumerate(("mnt4753_g1", "mnt4753_g2", "mnt6753_g1", "mnt6753_g2"))))
+def test_xyzz_mixed_addition(shim, cid, name):
+    """xyzz_madd / xyzz_to_proj (ec29.h: madd-2008-s on (X, Y, ZZ, ZZZ)) against the affine group law in Python: a chain of
+    additions, the empty accumulator, P + (-P) -> infinity, and P == Q reported through `same`."""
+    C = pyref.CURVES[name]
+    F, E, k = C.F, C.E, C.deg
+    rng = pyref.Rng(400 + cid)
+
+    def pack(parts):
+        buf = (U * (24 * k * len(parts)))()
+        for j, e in enumerate(parts):
+            for c in range(k):
+                w = words(F.to_mont(e[c]))
+                for i in range(24):
+                    buf[(j * k + c) * 24 + i] = w[i]
+        return buf
+
+    def xyzz(Pt):
+        if Pt is None:
+            return pack((E.zero(), E.one(), E.zero(), E.zero()))
+        z = tuple(rng.field_elem(F.p) for _ in range(k))
+        zz = E.mul(z, z)
+        zzz = E.mul(zz, z)
+        return pack((E.mul(Pt[0], zz), E.mul(Pt[1], zzz), zz, zzz))
+
+    def ext(out, j):
+        return tuple(F.from_mont(toint(out[(j * k + c) * 24:(j * k + c + 1) * 24])) for c in range(k))
+
+    def results(out):
+        X, Y, ZZ, ZZZ = (ext(out, j) for j in range(4))
+        if all(v == 0 for v in ZZ):
+            a1 = None
+        else:
+            a1 = (E.mul(X, E.inv(ZZ)), E.mul(Y, E.inv(ZZZ)))
+            assert E.mul(E.mul(ZZ, ZZ), ZZ) == E.mul(ZZZ, ZZZ)          # the invariant ZZ^3 = ZZZ^2
+        a2 = C.proj_to_affine(ext(out, 4), ext(out, 5), ext(out, 6))
+        assert a1 == a2
+        return a1
+
+    out = (U * (24 * k * 7))()
+    P, Q = C.mul(424242, C.G), C.mul(777777777, C.G)
+    for A, B in ((P, Q), (Q, P), (None, Q), (P, C.neg(P)), (C.add(P, Q), C.neg(Q))):
+        assert shim.t_xyzz_madd(cid, xyzz(A), pack(B), out) == 0
+        assert results(out) == C.add(A, B)
+    assert shim.t_xyzz_madd(cid, xyzz(P), pack(P), out) == 1            # P == Q: reported, accumulator unchanged
+    assert results(out) == P
+    acc = None
+    for j in range(6):                                                  # a running sum fed back in its own coordinates
+        B = C.mul(1000 + 37 * j, C.G)
+        buf = xyzz(acc)
+        assert shim.t_xyzz_madd(cid, buf, pack(B), out) == 0
+        acc = C.add(acc, B)
+        assert results(out) == acc
+
+
 @pytest.mark.parametrize("fid,F,curve", [(4, pyref.P4, "mnt4753_g1"), (6, pyref.P6, "mnt6753_g1")])
 def test_host_fold_field(shim, fid, F, curve):
     """the 12 x u64 host field used by the window fold (host_math.h HF1) and G1 add/double on it"""
