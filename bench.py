@@ -113,25 +113,40 @@ def main():
             return distmod.CDist(gl, rank, world, transport="callback", allgather=distmod.gloo_allgather_bytes(dist))
         if backend == "rccl":
             from torch.distributed.distributed_c10d import _get_default_store
+            import signal
             import torch
-            # bring the communicator up and push one exchange of the identity through it; every rank then agrees (over gloo)
-            # whether RCCL is usable.  If any rank saw an error the whole job drops to the callback transport, and says so.
-            err = ""
-            try:
-                cdist = distmod.CDist(gl, rank, world, transport="rccl", store=_get_default_store())
-                ident = np.zeros(36 * pyref.CURVES[args.curve].deg, dtype=np.uint64)
-                ident[12 * pyref.CURVES[args.curve].deg] = 1          # (0 : 1 : 0); any limbs do for the probe
-                cdist.allgather_fold(args.curve, ident)
-            except Exception as e:      # noqa: reported below
-                err = "%s: %s" % (type(e).__name__, e)
-            flag = torch.tensor([0 if err else 1])
+            # Step 1, local and collective-free: can THIS rank load and bind librccl?  The ranks agree on the answer over gloo
+            # BEFORE anyone enters ncclCommInitRank -- a rank that failed alone would otherwise leave the others blocked in it.
+            local_ok = distmod.CDist.probe_rccl(gl)
+            flag = torch.tensor([1 if local_ok else 0])
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) == 0:
-                sys.stderr.write("bench.py rank %d: RCCL exchange unavailable (%s); using the gloo callback transport\n" % (rank, err or "another rank failed"))
+            err = "" if int(flag.item()) else ("librccl not loadable: %s" % gl.load_library().gh_last_error().decode() if not local_ok else "librccl not loadable on another rank")
+            if not err:
+                # Step 2, collective, under a watchdog: a communicator that does not come up within two minutes ends the job
+                # with a non-zero status instead of hanging it.
+                def _watchdog(signum, frame):
+                    sys.stderr.write("bench.py rank %d: RCCL communicator did not come up within 120 s\n" % rank)
+                    os._exit(3)
+                signal.signal(signal.SIGALRM, _watchdog)
+                signal.alarm(120)
+                try:
+                    cdist = distmod.CDist(gl, rank, world, transport="rccl", store=_get_default_store())
+                    ident = np.zeros(36 * pyref.CURVES[args.curve].deg, dtype=np.uint64)
+                    ident[12 * pyref.CURVES[args.curve].deg] = 1          # (0 : 1 : 0); any limbs do for the probe
+                    cdist.allgather_fold(args.curve, ident)
+                except Exception as e:      # noqa: reported below
+                    err = "%s: %s" % (type(e).__name__, e)
+                signal.alarm(0)
+                flag = torch.tensor([0 if err else 1])
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if int(flag.item()) == 0 and not err:
+                    err = "RCCL failed on another rank"
+            if err:
+                sys.stderr.write("bench.py rank %d: RCCL exchange unavailable (%s); using the gloo callback transport\n" % (rank, err))
                 if cdist is not None:
                     cdist.shutdown()
                 cdist = _callback_transport()
-                exchange_note = "gloo callback (RCCL failed: %s)" % (err or "on another rank")
+                exchange_note = "gloo callback (RCCL unavailable: %s)" % err
         else:
             cdist = _callback_transport()
     if args.window:
@@ -155,10 +170,22 @@ def main():
     def chain_key(crv, count, seed):
         Cc = pyref.CURVES[crv]
         prng = pyref.Rng(seed)
-        xy, _ = S.bases_array(Cc, [Cc.mul(prng.next_u64() | 1, Cc.G), Cc.mul(prng.next_u64() | 1, Cc.G)])
-        return gl.ResidentBases.chain(crv, xy[0], xy[1], count)
+        p0, step = Cc.mul(prng.next_u64() | 1, Cc.G), Cc.mul(prng.next_u64() | 1, Cc.G)
+        xy, _ = S.bases_array(Cc, [p0, step])
+        return gl.ResidentBases.chain(crv, xy[0], xy[1], count), p0, step
 
-    rb = chain_key(curve, n, 1 + rank)
+    def closed_form_ok(crv, p0, step, sc, xyz):
+        """the MSM result against sum s_i (P_0 + i H) = (sum s_i) P_0 + (sum i s_i) H evaluated with Python integers
+        (tests/support.py: no MSM code path involved) -- an independent answer at the full size"""
+        Cc = pyref.CURVES[crv]
+        e_xy, e_inf = S.affine_abi_of_point(Cc, S.chain_msm_closed_form(Cc, p0, step, sc))
+        g_xy, g_inf = gl.proj_to_affine(crv, xyz)
+        return bool(g_inf == e_inf and (np.asarray(g_xy).reshape(-1) == e_xy).all())
+
+    t_key = time.perf_counter()
+    rb, key_p0, key_step = chain_key(curve, n, 1 + rank)
+    gl.load_library().gh_dev_sync()
+    key_generate_s = time.perf_counter() - t_key
     scalars = S.random_scalars_np(n, seed=1000 + rank, below=C.order)
     ds = gl.DeviceBuffer(n * 96).upload(scalars)
     # The bases are a proving key: uploaded once, outside the timed region (SURVEY.md 8d), and -- like the
@@ -166,27 +193,41 @@ def main():
     # The per-window path (no table) is timed as well and reported under "per_window_path".
     plain = None
     table_info = None
+    phases_alone = None
     if not args.no_precompute and not args.window:
         for _ in range(max(1, args.warmup)):
             rb.msm_dev(ds, n)
         gl.load_library().gh_dev_sync()
+        PW_STEPS = 5
         t0 = time.perf_counter()
-        for _ in range(2):
+        for _ in range(PW_STEPS):
             plain_out = rb.msm_dev(ds, n)
-        dt = (time.perf_counter() - t0) / 2
+        dt = (time.perf_counter() - t0) / PW_STEPS
         ptm = gl.msm_last_timing()
+        t0 = time.perf_counter()
+        gl.msm_batch_dev([(rb, ds, n)] * PW_STEPS)
+        dtb = (time.perf_counter() - t0) / PW_STEPS
         plain = {"value": n / dt, "unit": "scalar-muls/s per GPU", "ms_per_step": dt * 1e3, "window_bits": ptm["window_bits"],
-                 "num_windows": ptm["num_windows"], "accumulate_ms": ptm["accumulate_ms"], "steps": 2}
+                 "num_windows": ptm["num_windows"], "accumulate_ms": ptm["accumulate_ms"], "steps": PW_STEPS,
+                 "pipelined_batch": {"value": n / dtb, "ms_per_step": dtb * 1e3, "steps": PW_STEPS},
+                 "closed_form_ok": closed_form_ok(curve, key_p0, key_step, scalars, plain_out)}
         t0 = time.perf_counter()
         c_tab = rb.precompute(0)
         rows = 752 // c_tab + 1
         table_info = {"window_bits": c_tab, "rows": rows, "bytes": rows * n * 208 * C.deg, "build_s": time.perf_counter() - t0,
-                      "note": "one-time per resident key, outside the timed region (like the base upload)"}
+                      "key_generate_s": key_generate_s,
+                      "note": "one-time per resident key, outside the timed region (like the base upload); key_load_s = key_generate_s "
+                              "(synthetic chain on the device; a real key pays its upload instead) + build_s"}
+        table_info["key_load_s"] = key_generate_s + table_info["build_s"]
         a1 = gl.proj_to_affine(curve, rb.msm_dev(ds, n))
         t0 = time.perf_counter()
-        rb.msm_dev(ds, n)
-        rb.msm_dev(ds, n)
-        table_info["single_msm_ms"] = (time.perf_counter() - t0) / 2 * 1e3    # latency of one MSM, nothing to overlap with
+        solo_tm = []
+        for _ in range(5):
+            rb.msm_dev(ds, n)
+            solo_tm.append(gl.msm_last_timing())
+        table_info["single_msm_ms"] = (time.perf_counter() - t0) / 5 * 1e3    # latency of one MSM, nothing to overlap with
+        table_info["single_msm_steps"] = 5
+        phases_alone = {k: float(np.mean([t[k] for t in solo_tm])) for k in ("sort_ms", "accumulate_ms", "heavy_ms", "reduce_ms", "fold_ms")}
         plain["note"] = "no shift table, MSMs issued one by one"
         a0 = gl.proj_to_affine(curve, plain_out)
         plain["same_affine_result_as_table_path"] = bool(a0[1] == a1[1] and (a0[0] == a1[0]).all())
@@ -207,12 +248,15 @@ def main():
         else:
             partials = gl.msm_batch_dev([(rb, ds, n)] * k)
             tms = [gl.msm_batch_timing(i) for i in range(k)]
-        totals = [cdist.allgather_fold(curve, p) if world > 1 else p for p in partials]
+        # the partial sums of the whole batch travel in ONE all-gather (gh_partials_allgather_fold_batch), then k folds
+        totals = cdist.allgather_fold_batch(curve, partials) if world > 1 else partials
         if world > 1:
             exch_us.append(cdist.last_exchange_us)
+        own_partial[:] = [partials[-1]]
         return totals, tms
 
     exch_us = []
+    own_partial = []
 
     def sync():
         gl.load_library().gh_dev_sync()      # the library's streams (this process holds no other GPU work)
@@ -220,8 +264,9 @@ def main():
             dist.barrier()
 
     # which accumulation the library's automatic policy picked for this curve (include/ginger_hip.h: gh_msm_set_affine)
+    xyzz = C.deg == 1 and os.environ.get("GH_ACC_XYZZ", "1") != "0"
     bucket_mode = "affine rounds (aff_kernels.h) + projective finish" if (C.deg > 1 and os.environ.get("GH_AFFINE", "2") != "0") or os.environ.get("GH_AFFINE") == "1" \
-        else "projective mixed additions"
+        else ("XYZZ mixed additions (madd-2008-s, 8 M + 2 S, Y3 as one dual product)" if xyzz else "projective mixed additions")
     if args.warmup:
         run_steps(args.warmup)
     sync()
@@ -249,20 +294,32 @@ def main():
     madds = tm_last["accumulate_madds"]
     # base-field products per addition: projective mixed addition 11 (madd-1998-cmo); affine rounds 5 M + 1 S (+ the shared
     # inversion, not counted); tower fields: Fq2 product = 4 Fp products in the lane-pair form, Fq3 = 9
-    per_add = (6 if bucket_mode.startswith("affine") else 11) * {1: 1, 2: 4, 3: 9}[C.deg]
+    per_add = (6 if bucket_mode.startswith("affine") else (10 if xyzz else 11)) * {1: 1, 2: 4, 3: 9}[C.deg]
+    # every rank checks ITS partial sum (own key, own scalars) against the closed form; the line reports the AND over ranks
+    cf_ok = closed_form_ok(curve, key_p0, key_step, scalars, own_partial[0])
+    if world > 1:
+        import torch
+        f = torch.tensor([1 if cf_ok else 0])
+        dist.all_reduce(f, op=dist.ReduceOp.MIN)
+        cf_ok = bool(int(f.item()))
     fpmul_rate = madds * per_add / (acc_avg_ms * 1e-3)
 
     # HBM traffic per launch of the dominant kernels: PMC counters collected with rocprofv3 in separate
     # passes on this same command (profiles/r01_pmc_traffic.json); null if that file is absent or the
     # workload differs from the profiled one (2^20 pairs / 2^24 points).
     traffic_acc = traffic_ntt = None
-    traffic_src = "profiles/r02_pmc_traffic.json"
+    traffic_g2 = {}
+    traffic_src = "profiles/r03_pmc_traffic.json"
     try:
         tr = json.load(open(os.path.join(ROOT, traffic_src)))
         if tr.get("kernels_sha256") == kernels_sha():          # counters go stale when the kernels change: then null
             ent = tr.get("%s_2p%d" % (curve, n.bit_length() - 1))
             if ent and ent["window_bits"] == tm_last["window_bits"] and ent["bucket_sums"] == bucket_mode:
                 traffic_acc = ent["fetch_bytes_per_msm"] + ent["write_bytes_per_msm"]
+            for crv_g, lg_g in (("mnt4753_g2", 20), ("mnt6753_g2", 19)):
+                eg = tr.get("%s_2p%d" % (crv_g, lg_g))
+                if eg:
+                    traffic_g2[crv_g] = eg["fetch_bytes_per_msm"] + eg["write_bytes_per_msm"]
             ent = tr.get("ntt_2p%d" % args.ntt_log_n)
             if ent:
                 traffic_ntt = ent["fetch_bytes_per_transform"] + ent["write_bytes_per_transform"]
@@ -273,7 +330,7 @@ def main():
         "metric": "MNT4-753 G1 MSM scalar-muls/sec + 2^n NTT ms at 1/2/4/8 MI355X",
         "value": value,
         "unit": "scalar-muls/s",
-        "n_gpus": cdist.world_seen if cdist is not None else 1,
+        "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
@@ -288,7 +345,10 @@ def main():
                        " (2^%d in all, strong scaling)" % args.total_log_n if strong else ""),
                    "curve": curve, "pairs_per_gpu": n, "window_bits": tm_last["window_bits"], "num_windows": tm_last["num_windows"],
                    "resident_key_shift_table": table_info, "distinct_bases": n, "bucket_sums": bucket_mode, "parallelism": "pairs sharded by rank, 1 all-gather of partial sums" if world > 1 else "single GPU"},
-        "roofline": {"kernel": "msm_accumulate_kernel (bucket accumulation of the %s MSM)" % curve, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+        "closed_form_ok": cf_ok,
+        "closed_form_note": "each rank's partial sum of the last timed step == (sum s_i) P_0 + (sum i s_i) H on its chain key, evaluated with "
+                            "Python integers (tests/support.py chain_msm_closed_form): an answer no MSM code path produced",
+        "roofline": {"kernel": "%s (bucket accumulation of the %s MSM)" % ("msm_accumulate_xyzz_kernel" if xyzz else "msm_accumulate_kernel / aff_round_kernel", curve), "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_acc,
                      "traffic_note": "FETCH_SIZE + WRITE_SIZE bytes of the accumulation launches of one MSM from %s (separate rocprofv3 --pmc passes), null when that file was measured on other kernel sources (sha256 of ginger-lib_amd/csrc) or another workload" % traffic_src,
                      "avg_launch_ms": acc_avg_ms, "algorithmic_bytes_per_launch": alg_bytes,
@@ -297,54 +357,114 @@ def main():
                  "fp_products_per_addition": per_add,
                  "note": "peak = measured rr29 Montgomery-product microbenchmark (profiles/r01_microbench_valu_rates.txt)"},
         "phases_ms": phases,
+        "phases_alone_ms": phases_alone,
         "phases_note": "per-MSM device phases by HIP events on their streams; with the pipelined batch the phases of neighbouring "
-                       "steps overlap (sort and reduce run beside the previous / next accumulation), so they do not add up to ms_per_step",
+                       "steps overlap (sort and reduce run beside the previous / next accumulation) and are stretched by it, so they do not add "
+                       "up to ms_per_step; phases_alone_ms = the same phases of ONE MSM with nothing beside it (mean of 5)",
         "pipelined": not args.no_pipeline,
     }
     if world > 1:
         out["exchange"] = {"transport": exchange_note or ("rccl all-gather behind gh_partials_allgather_fold" if backend == "rccl" else "gloo (rehearsal)"),
-                           "ranks_seen_by_transport": cdist.world_seen, "bytes_per_rank": 288 * C.deg,
-                           "avg_us": float(np.mean(exch_us[-args.steps:])) if exch_us else None}
+                           "ranks_seen_by_transport": cdist.world_seen, "rccl_ranks": cdist.rccl_ranks,
+                           "rccl_ranks_note": "ncclCommCount of the live communicator; 0 = the exchange did NOT go over RCCL (callback transport)",
+                           "rccl_version": cdist.rccl_version, "rccl_path": cdist.rccl_path,
+                           "bytes_per_rank_and_msm": 288 * C.deg, "exchanges_per_timed_region": 1,
+                           "avg_us": float(np.mean(exch_us[-1:])) if exch_us else None,
+                           "note": "the partial sums of all timed steps travel in ONE all-gather after the batch; avg_us = that exchange"}
+    if not cf_ok:
+        out["error"] = "MSM result differs from the closed form on the chain key"
     if plain is not None:
         out["per_window_path"] = plain
         if not plain["same_affine_result_as_table_path"]:
             out["error"] = "table path and per-window path disagree"
+        if not plain["closed_form_ok"]:
+            out["error"] = "per-window path differs from the closed form"
+    # ---- what the UNCHANGED prover would see through the Rust shim (rust/algebra-hip-sys + rust/patches): prover.rs:273-325
+    #      issues its G1 MSMs one call after the other, each with (bases, scalars) host slices -> gh_msm_cached: the bases are
+    #      hashed on every call (identity = content), found resident, and only the scalars cross PCIe; nothing is pipelined.
+    #      Pageable host arrays, as a Vec is.  `handle_path` = the same four calls for a caller that holds the handle
+    #      (gh_msm_resident: no hash).
+    if rank == 0 and world == 1 and not args.window and not args.no_precompute:
+        host_s = [scalars, scalars[::-1].copy(), scalars.copy(), scalars[::-1].copy()]
+        host_bases = rb.download(0, n)
+        gl.key_cache_clear()
+        t0 = time.perf_counter()
+        gl.msm_cached(curve, host_bases, host_s[0])              # first sighting: upload, per-window path (what gh_msm costs)
+        first_ms = (time.perf_counter() - t0) * 1e3
+        t0 = time.perf_counter()
+        gl.msm_cached(curve, host_bases, host_s[0])              # second sighting: the key gets its shift table
+        second_ms = (time.perf_counter() - t0) * 1e3
+        gl.msm_cached(curve, host_bases, host_s[0])
+        t0 = time.perf_counter()
+        outs4 = [gl.msm_cached(curve, host_bases, h) for h in host_s]
+        dt4 = time.perf_counter() - t0
+        kst = gl.key_cache_stats()
+        gl.key_cache_clear()
+        rb.msm(host_s[0])
+        t0 = time.perf_counter()
+        outs4h = [rb.msm(h) for h in host_s]
+        dt4h = time.perf_counter() - t0
+        out["drop_in_path"] = {"workload": "4 sequential gh_msm_cached calls with host (bases, scalars) slices: the G1 MSM sequence of one create_proof "
+                                           "as the unchanged prover.rs:273-325 issues it through rust/algebra-hip-sys (bases hashed per call, "
+                                           "resident after the first proof, shift table from the second sighting)",
+                               "value": 4 * n / dt4, "unit": "scalar-muls/s", "ms_per_msm": dt4 / 4 * 1e3, "calls": 4, "pcie_inclusive": True,
+                               "first_sighting_ms": first_ms, "second_sighting_ms_incl_table_build": second_ms,
+                               "key_cache": kst,
+                               "handle_path": {"value": 4 * n / dt4h, "ms_per_msm": dt4h / 4 * 1e3,
+                                               "note": "gh_msm_resident on a caller-held handle: no packing, no hash"},
+                               "closed_form_ok": closed_form_ok(curve, key_p0, key_step, host_s[0], outs4[0])
+                                                 and closed_form_ok(curve, key_p0, key_step, host_s[1], outs4h[1])}
+        if not out["drop_in_path"]["closed_form_ok"]:
+            out["error"] = "drop-in path differs from the closed form"
+        del host_bases
 
     # ---- BASELINE config 3's second size: 2^24 pairs (per-window path and shift table c = 23, 115 GB), same line
     if not args.no_2p24 and rank == 0 and world == 1 and curve == "mnt4753_g1" and not args.window and args.log_n < 24:
         try:
             n24 = 1 << 24
-            rb24 = chain_key(curve, n24, 77)
+            rb24, p0_24, st_24 = chain_key(curve, n24, 77)
             s24 = S.random_scalars_np(n24, seed=2024, below=C.order)
             d24 = gl.DeviceBuffer(n24 * 96).upload(s24)
-            del s24
+            K24 = 5
             rb24.msm_dev(d24, n24)
             t1 = time.perf_counter()
-            p_out = rb24.msm_dev(d24, n24)
-            pw_ms = (time.perf_counter() - t1) * 1e3
+            for _ in range(K24):
+                p_out = rb24.msm_dev(d24, n24)
+            pw_ms = (time.perf_counter() - t1) * 1e3 / K24
             ptm = gl.msm_last_timing()
             t1 = time.perf_counter()
             c24 = rb24.precompute(0)
             build_s = time.perf_counter() - t1
             rb24.msm_dev(d24, n24)
             t1 = time.perf_counter()
-            t_out = rb24.msm_dev(d24, n24)
-            tb_ms = (time.perf_counter() - t1) * 1e3
+            for _ in range(K24):
+                t_out = rb24.msm_dev(d24, n24)
+            tb_ms = (time.perf_counter() - t1) * 1e3 / K24
             ttm = gl.msm_last_timing()
             t1 = time.perf_counter()
-            gl.msm_batch_dev([(rb24, d24, n24)] * 3)
-            bt_ms = (time.perf_counter() - t1) * 1e3 / 3
+            b_out = gl.msm_batch_dev([(rb24, d24, n24)] * K24)
+            bt_ms = (time.perf_counter() - t1) * 1e3 / K24
             a0, a1 = gl.proj_to_affine(curve, p_out), gl.proj_to_affine(curve, t_out)
+            cf24 = closed_form_ok(curve, p0_24, st_24, s24, b_out[-1]) and closed_form_ok(curve, p0_24, st_24, s24, p_out)
+            del s24
             out["msm_2p24"] = {
                 "workload": "MNT4-753 G1 VariableBaseMSM, 2^24 distinct pairs, resident",
                 "per_window_path": {"value": n24 / pw_ms * 1e3, "ms": pw_ms, "window_bits": ptm["window_bits"], "num_windows": ptm["num_windows"],
                                     "accumulate_ms": ptm["accumulate_ms"]},
                 "shift_table": {"value": n24 / tb_ms * 1e3, "ms": tb_ms, "window_bits": c24, "rows": 752 // c24 + 1,
                                 "bytes": (752 // c24 + 1) * n24 * 208, "build_s": build_s, "accumulate_ms": ttm["accumulate_ms"],
-                                "pipelined_batch_of_3": {"value": n24 / bt_ms * 1e3, "ms_per_msm": bt_ms}},
+                                "pipelined_batch": {"value": n24 / bt_ms * 1e3, "ms_per_msm": bt_ms, "steps": K24}},
+                "steps_per_figure": K24, "closed_form_ok": cf24,
+                "roofline": {"bound": "hbm", "achieved": 288.0 * n24 / (ttm["accumulate_ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": 288.0 * n24 / (ttm["accumulate_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                             "avg_launch_ms": ttm["accumulate_ms"], "algorithmic_bytes_per_launch": 288.0 * n24},
+                "valu": {"achieved_fpmul_per_s": ttm["accumulate_madds"] * per_add / (ttm["accumulate_ms"] * 1e-3), "peak_fpmul_per_s": FPMUL_PEAK_PER_S,
+                         "frac": ttm["accumulate_madds"] * per_add / (ttm["accumulate_ms"] * 1e-3) / FPMUL_PEAK_PER_S},
                 "unit": "scalar-muls/s", "same_affine_result": bool(a0[1] == a1[1] and (a0[0] == a1[0]).all())}
             if not out["msm_2p24"]["same_affine_result"]:
                 out["error"] = "2^24: table path and per-window path disagree"
+            if not cf24:
+                out["error"] = "2^24: result differs from the closed form"
             d24.free()
             rb24.free()
             gl.dev_trim()
@@ -358,24 +478,40 @@ def main():
             try:
                 ng = 1 << lg
                 Cg = pyref.CURVES[crv]
-                rbg = chain_key(crv, ng, 31)
-                dg = gl.DeviceBuffer(ng * 96).upload(S.random_scalars_np(ng, seed=4242, below=Cg.order))
+                rbg, p0g, stg = chain_key(crv, ng, 31)
+                sg = S.random_scalars_np(ng, seed=4242, below=Cg.order)
+                dg = gl.DeviceBuffer(ng * 96).upload(sg)
                 t1 = time.perf_counter()
                 cg = rbg.precompute(0)
                 build_s = time.perf_counter() - t1
                 rbg.msm_dev(dg, ng)
+                KG = 5
                 t1 = time.perf_counter()
-                rbg.msm_dev(dg, ng)
-                rbg.msm_dev(dg, ng)
-                one_ms = (time.perf_counter() - t1) / 2 * 1e3
+                for _ in range(KG):
+                    g_out = rbg.msm_dev(dg, ng)
+                one_ms = (time.perf_counter() - t1) / KG * 1e3
                 gtm = gl.msm_last_timing()
                 t1 = time.perf_counter()
-                gl.msm_batch_dev([(rbg, dg, ng)] * 3)
-                bt_ms = (time.perf_counter() - t1) * 1e3 / 3
+                gb_out = gl.msm_batch_dev([(rbg, dg, ng)] * KG)
+                bt_ms = (time.perf_counter() - t1) * 1e3 / KG
+                g_bytes = (192.0 * Cg.deg + 96.0) * ng
+                g_affine = os.environ.get("GH_AFFINE", "2") != "0"
+                g_per_add = (6 if g_affine else 11) * {2: 4, 3: 9}[Cg.deg]
                 out["g2"][crv] = {"workload": "%s VariableBaseMSM, 2^%d pairs, resident key with shift table" % (crv, lg),
+                                  "steps_per_figure": KG,
+                                  "closed_form_ok": closed_form_ok(crv, p0g, stg, sg, g_out) and closed_form_ok(crv, p0g, stg, sg, gb_out[-1]),
+                                  "roofline": {"kernel": "aff_round_kernel + projective finish (all accumulation launches of one MSM)", "bound": "hbm",
+                                               "achieved": g_bytes / (gtm["accumulate_ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                               "frac": g_bytes / (gtm["accumulate_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic_g2.get(crv),
+                                               "avg_launch_ms": gtm["accumulate_ms"], "algorithmic_bytes_per_launch": g_bytes},
+                                  "valu": {"achieved_fpmul_per_s": gtm["accumulate_madds"] * g_per_add / (gtm["accumulate_ms"] * 1e-3),
+                                           "peak_fpmul_per_s": FPMUL_PEAK_PER_S, "fp_products_per_addition": g_per_add,
+                                           "frac": gtm["accumulate_madds"] * g_per_add / (gtm["accumulate_ms"] * 1e-3) / FPMUL_PEAK_PER_S},
                                   "value": ng / bt_ms * 1e3, "unit": "scalar-muls/s", "ms_per_msm_pipelined": bt_ms, "single_msm_ms": one_ms,
                                   "window_bits": cg, "table_build_s": build_s, "bucket_sums": "affine rounds (aff_kernels.h) + projective finish" if os.environ.get("GH_AFFINE", "2") != "0" else "projective mixed additions",
                                   "phases_ms": {k: gtm[k] for k in ("sort_ms", "accumulate_ms", "reduce_ms", "fold_ms") if k in gtm}}
+                if not out["g2"][crv]["closed_form_ok"]:
+                    out["error"] = "%s: result differs from the closed form" % crv
                 dg.free()
                 rbg.free()
                 gl.dev_trim()
@@ -408,12 +544,15 @@ def main():
                       "roofline": {"kernel": "ntt_pass_kernel<P6> (all passes of one transform)", "bound": "hbm",
                                    "achieved": nb / (ntt_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": nb / (ntt_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic_ntt,
+                                   "traffic_note": "raw FETCH_SIZE + WRITE_SIZE; MI355X_MICROARCH.md: on gfx950 FETCH_SIZE under-reports wide coalesced "
+                                                   "streaming reads by 2x, so the true read traffic of these passes is up to twice the fetch part "
+                                                   "(profiles/r03_pmc_traffic.json holds fetch and write separately)",
                                    "algorithmic_bytes_per_transform": nb}}
 
     # ---- CPU baseline: the oracle (restated reference algorithm, C++) on the host cores, bounded sample
     if not args.no_cpu_baseline and rank == 0 and world == 1:
         cores = os.cpu_count() or 1
-        m = min(n, 1 << 16)        # BASELINE configs[0]: 2^16 pairs on the CPU path
+        m = n                      # the headline's own size (2^20 pairs: ~11 s on the box's host cores)
         import math
         c_ref = 3 if m < 32 else math.ceil(2.0 / 3.0 * math.log2(m) + 2.0)      # variable_base.rs:14-18
         msm_threads = min(cores, -(-753 // c_ref))                               # one task per window (:30-31)
@@ -433,7 +572,7 @@ def main():
                     break
         except OSError:
             pass
-        m1 = min(m, 1 << 12)       # the same algorithm on ONE core, smaller sample (c = 10 at 2^12, 76 windows in sequence)
+        m1 = min(m, 1 << 13)       # the same algorithm on ONE core, smaller sample (c = 11 at 2^13, 69 windows in sequence)
         t1 = time.perf_counter()
         S.oracle_msm(curve, bases[:m1], None, scalars[:m1], 1)
         cpu1_s = time.perf_counter() - t1
@@ -441,12 +580,13 @@ def main():
                                "cpu_model": cpu_model,
                                "single_core": {"value": m1 / cpu1_s, "unit": "scalar-muls/s", "cores": 1,
                                                "sample": "first 2^%d pairs, %.2f s" % (int(np.log2(m1)), cpu1_s)},
-                               "sample": "oracle (C++ restatement of variable_base.rs:10-83, window-parallel) on the first 2^%d pairs of the same inputs, %.2f s" % (int(np.log2(m)), cpu_s),
+                               "sample": "oracle (C++ restatement of variable_base.rs:10-83, one task per window as the reference: %d windows at c = %d) on %s of the same inputs, %.2f s" % (
+                                   -(-753 // c_ref), c_ref, "ALL 2^%d pairs" % int(np.log2(m)) if m == n else "the first 2^%d pairs" % int(np.log2(m)), cpu_s),
                                "gpu_matches_oracle_on_sample": parity}
         if not parity:
             out["error"] = "GPU result differs from the oracle on the CPU-baseline sample"
         if "ntt" in out:
-            ln = min(args.ntt_log_n, 20)
+            ln = min(args.ntt_log_n, 24)       # the GPU figure's own size (2^24: ~20-30 s of best_fft on 32 threads)
             a = S.random_scalars_np(1 << ln, seed=8, below=pyref.P6.p)
             t1 = time.perf_counter()
             fft_threads = min(cores, 32)     # best_fft splits into 2^floor(log2 threads) sub-FFTs and its O(n*P) gather grows with P

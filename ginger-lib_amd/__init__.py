@@ -31,6 +31,7 @@ ABI_SYMBOLS = [
     "gh_init", "gh_shutdown", "gh_last_error", "gh_device_name",
     "gh_msm", "gh_bases_upload", "gh_bases_upload_wire", "gh_bases_generate_chain", "gh_bases_download", "gh_bases_free", "gh_bases_len", "gh_bases_precompute", "gh_bases_precomputed_window",
     "gh_msm_resident", "gh_msm_resident_dev", "gh_msm_resident_dev_batch",
+    "gh_msm_cached", "gh_key_cache_config", "gh_key_cache_clear", "gh_key_cache_stats", "gh_bases_content_hash",
     "gh_msm_set_window", "gh_msm_set_affine", "gh_msm_get_window", "gh_msm_last_timing", "gh_msm_batch_timing",
     "gh_domain_supported", "gh_fft", "gh_fft_dev", "gh_vec_mul_dev", "gh_vec_sub_dev", "gh_vec_scale_dev",
     "gh_vec_mul", "gh_vec_scale", "gh_fft_last_kernel_ms", "gh_witness_map", "gh_witness_map_dev",
@@ -41,8 +42,8 @@ ABI_SYMBOLS = [
     "gh_fixed_base_window", "gh_fixed_base_table", "gh_fixed_base_msm", "gh_fixed_base_free",
 ]
 # include/ginger_hip_dist.h
-DIST_SYMBOLS = ["gh_dist_unique_id", "gh_dist_init_rccl", "gh_dist_init_custom", "gh_dist_info", "gh_partials_allgather_fold",
-                "gh_dist_shutdown"]
+DIST_SYMBOLS = ["gh_dist_unique_id", "gh_dist_probe_rccl", "gh_dist_init_rccl", "gh_dist_init_custom", "gh_dist_info", "gh_dist_transport",
+                "gh_partials_allgather_fold", "gh_partials_allgather_fold_batch", "gh_dist_shutdown"]
 ALLGATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t)
 
 
@@ -55,6 +56,10 @@ class MsmTiming(ctypes.Structure):
                 ("reduce_ms", ctypes.c_float), ("fold_ms", ctypes.c_float), ("total_ms", ctypes.c_float),
                 ("window_bits", ctypes.c_int), ("num_windows", ctypes.c_int), ("accumulate_madds", ctypes.c_ulonglong),
                 ("heavy_buckets", ctypes.c_uint)]
+
+
+class KeyCacheStats(ctypes.Structure):
+    _fields_ = [(k, ctypes.c_uint64) for k in ("entries", "bytes", "hits", "misses", "evictions", "tables_built")]
 
 
 _lib = None
@@ -88,6 +93,11 @@ def load_library():
     lib.gh_msm_resident.argtypes = [vp, vp, sz, vp]
     lib.gh_msm_resident_dev.argtypes = [vp, vp, sz, vp]
     lib.gh_msm_resident_dev_batch.argtypes = [vp, vp, vp, ci, vp]
+    lib.gh_msm_cached.argtypes = [ci, vp, vp, sz, vp, sz, vp]
+    lib.gh_key_cache_config.argtypes = [sz, ci]
+    lib.gh_key_cache_stats.argtypes = [ctypes.POINTER(KeyCacheStats)]
+    lib.gh_bases_content_hash.argtypes = [ci, vp, vp, sz, ctypes.POINTER(ctypes.c_uint64)]
+    lib.gh_bases_content_hash.restype = ctypes.c_uint64
     lib.gh_msm_set_window.argtypes = [ci]
     lib.gh_msm_set_affine.argtypes = [ci]
     lib.gh_msm_get_window.argtypes = [ci, sz]
@@ -127,6 +137,8 @@ def load_library():
     lib.gh_dist_init_custom.argtypes = [ALLGATHER_FN, vp, ci, ci]
     lib.gh_dist_info.argtypes = [ctypes.POINTER(ci), ctypes.POINTER(ci)]
     lib.gh_partials_allgather_fold.argtypes = [ci, vp, vp, ctypes.POINTER(ctypes.c_double)]
+    lib.gh_partials_allgather_fold_batch.argtypes = [ci, vp, sz, vp, ctypes.POINTER(ctypes.c_double)]
+    lib.gh_dist_transport.argtypes = [ctypes.POINTER(ci), ctypes.POINTER(ci), ctypes.c_char_p, sz]
     _lib = lib
     return lib
 
@@ -188,6 +200,43 @@ class DeviceBuffer:
         if self.ptr:
             load_library().gh_dev_free(self.ptr)
             self.ptr = ctypes.c_void_p()
+
+
+def msm_cached(curve, bases, scalars, infinity=None):
+    """VariableBaseMSM::multi_scalar_mul for an unchanged caller (gh_msm_cached): a pure function of (bases, scalars) whose
+    bases stay resident between calls, identified by a hash over all of their limbs -- never by address."""
+    deg = CURVE_DEG[curve]
+    bases = _u64(bases, 24 * deg)
+    scalars = _u64(scalars, 12)
+    inf = None if infinity is None else np.ascontiguousarray(infinity, dtype=np.uint8)
+    out = np.zeros(36 * deg, dtype=np.uint64)
+    _check(load_library().gh_msm_cached(CURVES[curve], _ptr(bases), _ptr(inf) if inf is not None else None, bases.size // (24 * deg),
+                                        _ptr(scalars), scalars.size // 12, _ptr(out)))
+    return out
+
+
+def key_cache_config(max_bytes=64 << 30, table_after=2):
+    _check(load_library().gh_key_cache_config(int(max_bytes), int(table_after)))
+
+
+def key_cache_clear():
+    _check(load_library().gh_key_cache_clear())
+
+
+def key_cache_stats():
+    st = KeyCacheStats()
+    _check(load_library().gh_key_cache_stats(ctypes.byref(st)))
+    return {k: int(getattr(st, k)) for k, _ in KeyCacheStats._fields_}
+
+
+def bases_content_hash(curve, bases, infinity=None):
+    """(lo, hi) of the 128-bit hash gh_msm_cached keys on; host-only"""
+    deg = CURVE_DEG[curve]
+    bases = _u64(bases, 24 * deg)
+    inf = None if infinity is None else np.ascontiguousarray(infinity, dtype=np.uint8)
+    hi = ctypes.c_uint64(0)
+    lo = load_library().gh_bases_content_hash(CURVES[curve], _ptr(bases), _ptr(inf) if inf is not None else None, bases.size // (24 * deg), ctypes.byref(hi))
+    return int(lo), int(hi.value)
 
 
 class ResidentBases:

@@ -1,6 +1,7 @@
 // ginger_hip.hip -- the C ABI declared in include/ginger_hip.h plus the process-wide runtime
 // (device context, workspace pool, prefix scan).  Per-curve MSM code lives in msm_<curve>.hip,
 // the transforms in ntt.hip.  Build: __graft_entry__.py build() (hipcc --offload-arch=gfx950).
+#include <thread>
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
@@ -146,6 +147,7 @@ int gh_init(const int* devices, int n_devices) {
 
 int gh_shutdown(void) {
     std::lock_guard<std::mutex> lk(g_mu);
+    dist_teardown_locked();              // a communicator must not outlive the streams and the device binding it was made on
     if (!g.ready) return GH_OK;
     hipStreamSynchronize(g.stream);
     hipStreamSynchronize(g.stream_acc);
@@ -332,6 +334,200 @@ int gh_msm_resident(gh_bases_t handle, const uint64_t* scalars, size_t n_scalars
         HIPCHK(hipMemcpyAsync(d_s, scalars, n * 96, hipMemcpyHostToDevice, g.stream));
     }
     return ops->run(h, d_s, n, out_xyz);
+}
+
+// ------------------------------------------------------------------------------------------
+// Content-addressed resident keys.  VariableBaseMSM::multi_scalar_mul (variable_base.rs:85-90) is a pure function of its
+// two slices, and the prover calls it with the same proving-key queries proof after proof.  gh_msm_cached keeps that
+// contract and still moves only the scalars on a repeat: the bases are identified by a 128-bit hash over EVERY limb and
+// infinity flag (never by their address: a buffer reused with other bases is another key), a hit is served from the
+// resident copy, a miss is uploaded and remembered.  The cache is bounded (LRU by device bytes); the shift table is
+// built from the `table_after`-th sighting on (default 2: what is seen twice is a proving key, what is seen once pays
+// exactly what gh_msm pays).
+namespace {
+struct KeyHash { uint64_t a, b; };
+inline uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+// two independent multiply-rotate lanes over 64-bit words (not cryptographic: the inputs are not adversarial, the point
+// is that equal hashes mean equal bases for any two keys a process meets)
+inline void hash_words(const uint64_t* w, size_t n, uint64_t& h1, uint64_t& h2) {
+    for (size_t i = 0; i < n; i++) {
+        h1 = rotl64((h1 ^ w[i]) * 0x9E3779B97F4A7C15ull, 29) + 0xD6E8FEB86659FD93ull;
+        h2 = (rotl64(h2, 31) + w[i]) * 0xC2B2AE3D27D4EB4Full ^ (h2 >> 33);
+    }
+}
+KeyHash content_hash(gh_curve_t curve, const uint64_t* bases, const uint8_t* infinity, size_t n) {
+    const int deg = curve == GH_MNT4753_G2 ? 2 : (curve == GH_MNT6753_G2 ? 3 : 1);
+    const size_t words = n * (size_t)24 * deg;
+    // chunks hashed in parallel, then the chunk hashes are hashed in order
+    const size_t chunk = (size_t)1 << 16;
+    const size_t n_chunks = (words + chunk - 1) / chunk;
+    std::vector<uint64_t> ch(2 * n_chunks + 4);
+    unsigned nt = std::thread::hardware_concurrency();
+    if (nt == 0) nt = 1;
+    if (nt > 16) nt = 16;
+    if (nt > n_chunks) nt = n_chunks ? (unsigned)n_chunks : 1;
+    auto work = [&](unsigned t) {
+        for (size_t c = t; c < n_chunks; c += nt) {
+            uint64_t h1 = 0x243F6A8885A308D3ull + c, h2 = 0x13198A2E03707344ull ^ c;
+            const size_t lo = c * chunk, len = words - lo < chunk ? words - lo : chunk;
+            hash_words(bases + lo, len, h1, h2);
+            ch[2 * c] = h1; ch[2 * c + 1] = h2;
+        }
+    };
+    if (nt <= 1) work(0);
+    else {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; t++) th.emplace_back(work, t);
+        for (auto& x : th) x.join();
+    }
+    uint64_t h1 = 0xA4093822299F31D0ull ^ (uint64_t)curve, h2 = 0x082EFA98EC4E6C89ull + n;
+    hash_words(ch.data(), 2 * n_chunks, h1, h2);
+    if (infinity) {   // flags as 0 / 1 words, eight per word; an all-zero flag array hashes like a missing one
+        uint64_t acc = 0, any = 0;
+        std::vector<uint64_t> fw((n + 63) / 64 + 1, 0);
+        for (size_t i = 0; i < n; i++) if (infinity[i]) { fw[i >> 6] |= 1ull << (i & 63); any = 1; }
+        (void)acc;
+        if (any) hash_words(fw.data(), fw.size(), h1, h2);
+    }
+    return KeyHash{h1, h2};
+}
+struct CachedKey {
+    gh_curve_t curve;
+    size_t n;
+    KeyHash h;
+    BasesBase* key;
+    uint64_t stamp;       // LRU clock
+    uint32_t sightings;
+    size_t bytes;         // device bytes held (points + flags + table)
+};
+struct KeyCache {
+    std::vector<CachedKey> e;
+    uint64_t clock = 0;
+    size_t max_bytes = (size_t)64 << 30;     // of the 288 GB
+    int table_after = 2;                      // build the shift table at this sighting (0 = never)
+    gh_key_cache_stats_t st{};
+    bool registered = false;
+};
+KeyCache kc;
+size_t key_bytes(const BasesBase* h) {
+    const int deg = h->curve == GH_MNT4753_G2 ? 2 : (h->curve == GH_MNT6753_G2 ? 3 : 1);
+    const size_t pt = (size_t)208 * deg;
+    return h->n * pt + (h->d_inf ? h->n : 0) + (h->d_table ? (size_t)h->pre_W * h->n * pt : 0);
+}
+void free_key(BasesBase* h) {
+    if (!h) return;
+    if (h->d_points) hipFree(h->d_points);
+    if (h->d_inf) hipFree(h->d_inf);
+    if (h->d_table) hipFree(h->d_table);
+    h->magic = 0;
+    delete h;
+}
+void cache_drop_all() {
+    for (auto& k : kc.e) free_key(k.key);
+    kc.e.clear();
+    kc.st.entries = 0; kc.st.bytes = 0;
+}
+// evict least recently used entries (never `keep`) until the cache fits its budget
+void cache_fit(const BasesBase* keep) {
+    for (;;) {
+        size_t total = 0;
+        for (auto& k : kc.e) total += k.bytes;
+        kc.st.bytes = total; kc.st.entries = kc.e.size();
+        if (total <= kc.max_bytes) return;
+        size_t victim = kc.e.size();
+        for (size_t i = 0; i < kc.e.size(); i++)
+            if (kc.e[i].key != keep && (victim == kc.e.size() || kc.e[i].stamp < kc.e[victim].stamp)) victim = i;
+        if (victim == kc.e.size()) return;           // only `keep` is left: a key larger than the budget stays for this call
+        hipStreamSynchronize(g.stream); hipStreamSynchronize(g.stream_acc); hipStreamSynchronize(g.stream_red);
+        free_key(kc.e[victim].key);
+        kc.e.erase(kc.e.begin() + (long)victim);
+        kc.st.evictions++;
+    }
+}
+}  // namespace
+
+uint64_t gh_bases_content_hash(gh_curve_t curve, const uint64_t* bases, const uint8_t* infinity, size_t n_bases, uint64_t* hi) {
+    if (n_bases && !bases) return 0;
+    const KeyHash h = content_hash(curve, bases, infinity, n_bases);
+    if (hi) *hi = h.b;
+    return h.a;
+}
+
+int gh_key_cache_config(size_t max_bytes, int table_after) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (table_after < 0) { g_err = "table_after must be >= 0"; return GH_E_BAD_ARG; }
+    kc.max_bytes = max_bytes;
+    kc.table_after = table_after;
+    if (g.ready) cache_fit(nullptr);
+    return GH_OK;
+}
+int gh_key_cache_clear(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g.ready) { hipStreamSynchronize(g.stream); hipStreamSynchronize(g.stream_acc); hipStreamSynchronize(g.stream_red); }
+    cache_drop_all();
+    return GH_OK;
+}
+int gh_key_cache_stats(gh_key_cache_stats_t* out) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!out) { g_err = "null argument"; return GH_E_BAD_ARG; }
+    *out = kc.st;
+    return GH_OK;
+}
+
+int gh_msm_cached(gh_curve_t curve, const uint64_t* bases, const uint8_t* infinity, size_t n_bases, const uint64_t* scalars,
+                  size_t n_scalars, uint64_t* out_xyz) {
+    if (!out_xyz || (n_bases && !bases) || (n_scalars && !scalars)) {
+        std::lock_guard<std::mutex> lk(g_mu);
+        g_err = "null argument";
+        return GH_E_BAD_ARG;
+    }
+    // like msm_inner's zip (variable_base.rs:31), only the first min(n_bases, n_scalars) bases take part: they are the key
+    const size_t n = n_bases < n_scalars ? n_bases : n_scalars;
+    const KeyHash hh = content_hash(curve, bases, infinity, n);     // outside the lock: pure host work
+    std::lock_guard<std::mutex> lk(g_mu);
+    const MsmOps* ops = ops_of(curve);
+    if (!ops) return GH_E_BAD_ARG;
+    int rc = ensure_init();
+    if (rc) return rc;
+    if (!kc.registered) {
+        kc.registered = true;
+        g.at_shutdown.push_back([] { cache_drop_all(); kc.registered = false; });
+    }
+    CachedKey* hit = nullptr;
+    for (auto& k : kc.e) if (k.curve == curve && k.n == n && k.h.a == hh.a && k.h.b == hh.b) { hit = &k; break; }
+    if (!hit) {
+        kc.st.misses++;
+        BasesBase* h = nullptr;
+        rc = ops->upload(bases, infinity, n, 0, &h);
+        if (rc == GH_E_NOMEM && !kc.e.empty()) {      // the cache is only a cache: make room and try once more
+            (void)hipGetLastError();
+            hipStreamSynchronize(g.stream); hipStreamSynchronize(g.stream_acc); hipStreamSynchronize(g.stream_red);
+            cache_drop_all();
+            rc = ops->upload(bases, infinity, n, 0, &h);
+        }
+        if (rc) return rc;
+        kc.e.push_back(CachedKey{curve, n, hh, h, 0, 0, key_bytes(h)});
+        hit = &kc.e.back();
+    } else {
+        kc.st.hits++;
+    }
+    hit->stamp = ++kc.clock;
+    hit->sightings++;
+    BasesBase* key = hit->key;
+    if (kc.table_after > 0 && hit->sightings == (uint32_t)kc.table_after && !key->d_table && n >= 4096) {
+        const int prc = ops->precompute(key, 0);      // optional: NOMEM / UNSUPPORTED leave the key on the per-window path
+        if (prc == GH_OK) kc.st.tables_built++;
+        else (void)hipGetLastError();
+        hit->bytes = key_bytes(key);
+    }
+    cache_fit(key);                                   // may erase other entries: `hit` is not used below
+    void* d_s = nullptr;
+    if (n > 0) {
+        rc = pool_get("scalars", n * 96, &d_s);
+        if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(d_s, scalars, n * 96, hipMemcpyHostToDevice, g.stream));
+    }
+    return ops->run(key, d_s, n, out_xyz);
 }
 
 int gh_msm_set_window(int c) {

@@ -57,6 +57,7 @@ size_t pool_cap(const char* name);                 // current capacity of a cach
 void pool_release(const char* prefix);             // free every cached buffer whose name starts with prefix ("" = all)
 int device_scan(const uint32_t* in, uint32_t* out, size_t n, const char* tmpname, hipStream_t stream = nullptr);   // nullptr: g.stream
 int auto_window(size_t n, int deg);
+void dist_teardown_locked();                      // dist.hip: gh_shutdown (API lock held) destroys the communicator with the context
 
 #define HIPCHK(call)                                                                         \
     do {                                                                                     \

@@ -44,6 +44,11 @@ class CDist:
     through `store` (a torch.distributed store, e.g. the TCPStore torchrun's MASTER_ADDR / MASTER_PORT give);
     transport = "callback": any all-gather as a Python callable (gloo in the CPU tests)."""
 
+    @staticmethod
+    def probe_rccl(gl):
+        """True if librccl can be loaded and bound on THIS rank (no collective: safe to call before the ranks agree)"""
+        return gl.load_library().gh_dist_probe_rccl() == 0
+
     def __init__(self, gl, rank, world, transport="rccl", store=None, allgather=None):
         import ctypes
         self.gl, self.rank, self.world = gl, rank, world
@@ -72,6 +77,12 @@ class CDist:
         gl._check(lib.gh_dist_info(ctypes.byref(r), ctypes.byref(w)))
         self.world_seen = w.value              # ranks the transport itself reports (ncclCommCount)
         self.last_exchange_us = 0.0
+        rr, rv = ctypes.c_int(), ctypes.c_int()
+        path = ctypes.create_string_buffer(512)
+        gl._check(lib.gh_dist_transport(ctypes.byref(rr), ctypes.byref(rv), path, 512))
+        self.rccl_ranks = rr.value             # 0 on the callback transport: nothing went over RCCL
+        self.rccl_version = rv.value
+        self.rccl_path = path.value.decode()
 
     def allgather_fold(self, curve, partial_xyz):
         import ctypes
@@ -82,6 +93,19 @@ class CDist:
         gl._check(gl.load_library().gh_partials_allgather_fold(gl.CURVES[curve], gl._ptr(p), gl._ptr(out), ctypes.byref(us)))
         self.last_exchange_us = us.value
         return out
+
+    def allgather_fold_batch(self, curve, partials):
+        """the results of a pipelined batch in ONE exchange: list of partial sums in, list of global sums out"""
+        import ctypes
+        gl = self.gl
+        if not partials:
+            return []
+        p = np.ascontiguousarray(np.stack([np.asarray(x, dtype=np.uint64) for x in partials]))
+        out = np.zeros_like(p)
+        us = ctypes.c_double()
+        gl._check(gl.load_library().gh_partials_allgather_fold_batch(gl.CURVES[curve], gl._ptr(p), len(partials), gl._ptr(out), ctypes.byref(us)))
+        self.last_exchange_us = us.value
+        return [out[i].copy() for i in range(len(partials))]
 
     def shutdown(self):
         self.gl.load_library().gh_dist_shutdown()

@@ -117,6 +117,27 @@ int gh_bases_precompute(gh_bases_t handle, int window_bits);
 int gh_bases_precomputed_window(gh_bases_t handle); /* c of the table, 0 if none */
 /* scalars on the host */
 int gh_msm_resident(gh_bases_t handle, const uint64_t* scalars, size_t n_scalars, uint64_t* out_xyz);
+
+/* ---- content-addressed resident keys: the drop-in for an UNCHANGED caller of VariableBaseMSM::multi_scalar_mul
+ * (algebra/src/msm/variable_base.rs:85-90), which hands over (bases, scalars) slices on every call.
+ * gh_msm_cached has gh_msm's signature and gh_msm's result -- a pure function of its arguments -- but remembers the
+ * bases it has seen: they are identified by a 128-bit hash over EVERY coordinate limb and infinity flag of the first
+ * min(n_bases, n_scalars) bases (never by address: a buffer reused for other bases is another key), a repeat moves only
+ * the scalars, a new key is uploaded like gh_msm does.  From the table_after-th sighting of a key (default 2; >= 4096 bases)
+ * its shift table (gh_bases_precompute) is built.  The cache is bounded: least recently used keys are freed once the
+ * device bytes held exceed max_bytes (default 64 GiB); it is emptied by gh_key_cache_clear and by gh_shutdown.
+ * rust/algebra-hip-sys binds multi_scalar_mul to this entry point.                                  */
+typedef struct {
+    uint64_t entries, bytes;          /* keys resident now, device bytes they hold (points + flags + shift tables) */
+    uint64_t hits, misses, evictions, tables_built;
+} gh_key_cache_stats_t;
+int gh_msm_cached(gh_curve_t curve, const uint64_t* bases, const uint8_t* infinity, size_t n_bases,
+                  const uint64_t* scalars, size_t n_scalars, uint64_t* out_xyz);
+int gh_key_cache_config(size_t max_bytes, int table_after /* 0 = never build tables */);
+int gh_key_cache_clear(void);
+int gh_key_cache_stats(gh_key_cache_stats_t* out);
+/* The hash gh_msm_cached keys on (low half returned, high half through *hi if not NULL).  Host-only: needs no device. */
+uint64_t gh_bases_content_hash(gh_curve_t curve, const uint64_t* bases, const uint8_t* infinity, size_t n_bases, uint64_t* hi);
 /* scalars already in device memory (from gh_dev_alloc); used by the benchmark's HBM-resident timing
  * and by a device-resident prover pipeline.  The call is synchronous on the library stream. */
 int gh_msm_resident_dev(gh_bases_t handle, const void* d_scalars, size_t n_scalars, uint64_t* out_xyz);

@@ -36,14 +36,31 @@ int gh_dist_init_rccl(const void* id128, int rank, int world);
 typedef int (*gh_allgather_fn)(void* ctx, const void* send, void* recv, size_t bytes);
 int gh_dist_init_custom(gh_allgather_fn fn, void* ctx, int rank, int world);
 
+/* Loads and binds librccl without creating anything (no collective): lets every rank find out LOCALLY whether RCCL is
+ * usable before the ranks agree -- over the launcher's own channel -- to enter the collective gh_dist_init_rccl, where a
+ * rank that failed alone would leave the others waiting.  Resolution: an RCCL already mapped into the process (a host that
+ * imported torch carries torch's copy; two RCCLs in one process are one too many), else $GH_RCCL_PATH, else
+ * $ROCM_PATH/lib/librccl.so.1 (/opt/rocm), else the bare soname. */
+int gh_dist_probe_rccl(void);
+
 /* rank / world of the communicator (world as RCCL reports it: ncclCommCount); GH_E_DIST if none. */
 int gh_dist_info(int* rank, int* world);
+/* What actually carries the exchange: *rccl_ranks = ncclCommCount of the live RCCL communicator, 0 when the transport is a
+ * custom callback (or there is none); *rccl_version = ncclGetVersion of the bound librccl (0: none bound); path = the file
+ * its symbols come from.  Any pointer may be NULL. */
+int gh_dist_transport(int* rccl_ranks, int* rccl_version, char* path, size_t path_cap);
 
 /* out = partial(rank 0) + partial(rank 1) + ... + partial(world - 1), the same on every rank.
  * partial_xyz / out_xyz: projective MSM results in the ABI format (3 * 12 * deg u64); they may alias.
  * *exchange_us (may be NULL) receives the duration of the all-gather alone, microseconds. */
 int gh_partials_allgather_fold(gh_curve_t curve, const uint64_t* partial_xyz, uint64_t* out_xyz, double* exchange_us);
 
+/* The same for `count` partial sums at once (the results of a pipelined batch of MSMs, gh_msm_resident_dev_batch): ONE
+ * all-gather of count * 36 * deg u64 per rank, then count folds.  partials_xyz / outs_xyz: count x (36 * deg) u64, may
+ * alias.  *exchange_us: the all-gather(s) alone. */
+int gh_partials_allgather_fold_batch(gh_curve_t curve, const uint64_t* partials_xyz, size_t count, uint64_t* outs_xyz, double* exchange_us);
+
+/* Destroys the communicator (also done by gh_shutdown). */
 int gh_dist_shutdown(void);
 
 #ifdef __cplusplus

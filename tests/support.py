@@ -207,3 +207,55 @@ def oracle_sap_witness_map(field, a, c, d1, d2, threads=8):
     d1, d2 = (np.ascontiguousarray(x, dtype=np.uint64) for x in (d1, d2))
     assert oracle().oracle_sap_witness_map(FIELD_ID[field], ptr(a), ptr(c), n.bit_length() - 1, ptr(d1), ptr(d2), ptr(h), threads) == 0
     return h
+
+
+# ---- closed form of an MSM over a chain key (first principles: independent of every MSM code path)
+def chain_sums(scalars, modulus, chunk=1 << 18):
+    """(sum_i s_i mod r, sum_i i * s_i mod r) for n x 12 u64 scalars, exactly, with numpy: the limbs are cut into 16-bit
+    pieces and the index into 12-bit pieces, so that every dot product of a chunk (<= 2^18 rows) stays below
+    2^12 * 2^16 * 2^18 = 2^46 and is exact in float64 (BLAS); the chunk results are added as Python integers."""
+    s = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 12)
+    n = len(s)
+    assert chunk <= 1 << 18 and n < 1 << 36
+    s0 = 0
+    s1 = 0
+    weights = [1 << (16 * j) for j in range(48)]
+    buf = np.empty((min(n, chunk), 48), dtype=np.float64)             # reused: a fresh 100 MB array per chunk costs more than the math
+    for lo in range(0, n, chunk):
+        blk = s[lo:lo + chunk]
+        m = len(blk)
+        pieces = buf[:m]
+        np.copyto(pieces, blk.view(np.uint16))                        # m x 48, little endian: piece j has weight 2^(16 j)
+        idx = np.arange(lo, lo + m, dtype=np.uint64)
+        rows = [np.ones(m, dtype=np.float64)]
+        shifts = []
+        for part in range(0, 36, 12):                                 # the index in 12-bit pieces
+            ip = (idx >> np.uint64(part)) & np.uint64(0xFFF)
+            if ip.any():
+                rows.append(ip.astype(np.float64))
+                shifts.append(part)
+        prod = pieces.T @ np.stack(rows).T                            # 48 x (1 + parts), every entry an exact integer < 2^46
+        s0 += sum(int(prod[j, 0]) * weights[j] for j in range(48))
+        for k, part in enumerate(shifts):
+            s1 += sum(int(prod[j, 1 + k]) * weights[j] for j in range(48)) << part
+    return s0 % modulus, s1 % modulus
+
+
+def chain_msm_closed_form(C, P0, H, scalars):
+    """sum_i s_i (P0 + i H) = (sum s_i) P0 + (sum i s_i) H, as an affine point (or None) -- two scalar multiplications with
+    Python integers (pyref), the reference's own MSM test idea (variable_base.rs:102-151: Pippenger == naive sum)."""
+    a, b = chain_sums(scalars, C.order)
+    return C.add(C.mul(a, P0) if a else None, C.mul(b, H) if b else None)
+
+
+def affine_abi_of_point(C, P):
+    """(xy words, infinity flag) in the form gh_proj_to_affine returns, for an affine pyref point"""
+    if P is None:
+        xy, _ = bases_array(C, [None])
+        k = C.deg
+        one = pyref.ext_to_abi(C.F, C.E.one())
+        out = np.zeros(24 * k, dtype=np.uint64)
+        out[12 * k:] = one
+        return out, True
+    xy, _ = bases_array(C, [P])
+    return xy[0], False

@@ -24,7 +24,7 @@ def test_every_declared_symbol_is_exported(gl):
         assert hasattr(lib, n), n
     assert sorted(gl.ABI_SYMBOLS) == names
     dist = header_functions("ginger_hip_dist.h")
-    assert len(dist) == 6 and sorted(gl.DIST_SYMBOLS) == dist
+    assert len(dist) == 9 and sorted(gl.DIST_SYMBOLS) == dist
     for n in dist:
         assert hasattr(lib, n), n
 
@@ -54,6 +54,48 @@ def test_host_only_entry_points_work_without_gpu(gl):
     assert lib.gh_domain_supported(0, 0, ctypes.byref(lg)) == 1 and lg.value == 0
 
 
+def test_key_cache_identifies_bases_by_content(gl):
+    """gh_msm_cached (the drop-in for multi_scalar_mul, a pure function: variable_base.rs:85-90) keys its resident copies
+    on a hash over ALL limbs: two different base sets passed through ONE buffer -- same address, same length, same first
+    and last rows, only an interior limb differs -- are two keys; equal content at another address is the same key.
+    Host-only part (the hash and the bookkeeping entry points need no device)."""
+    rng = np.random.default_rng(5)
+    for curve, deg in (("mnt4753_g1", 1), ("mnt6753_g2", 3)):
+        n = 70000                                   # several hash chunks (2^16 words each), hashed on several threads
+        buf = rng.integers(0, 1 << 63, size=(n, 24 * deg), dtype=np.uint64)
+        addr = buf.ctypes.data
+        h0 = gl.bases_content_hash(curve, buf)
+        assert h0 == gl.bases_content_hash(curve, buf)                       # deterministic across calls / thread schedules
+        copy = buf.copy()
+        assert copy.ctypes.data != addr and gl.bases_content_hash(curve, copy) == h0
+        seen = {h0}
+        for row, col in ((n // 2, 7), (1, 0), (n - 2, 24 * deg - 1), (65536 // (24 * deg), 3)):
+            old = buf[row, col]
+            buf[row, col] ^= np.uint64(1)                                    # in-place mutation: same address, same ends
+            assert buf.ctypes.data == addr
+            h = gl.bases_content_hash(curve, buf)
+            assert h not in seen and h[0] != h0[0] and h[1] != h0[1]
+            seen.add(h)
+            buf[row, col] = old
+        assert gl.bases_content_hash(curve, buf) == h0
+        # rows swapped: same multiset of limbs, another key; a shorter prefix: another key
+        buf[[10, 11]] = buf[[11, 10]]
+        assert gl.bases_content_hash(curve, buf) not in seen
+        assert gl.bases_content_hash(curve, buf[: n - 1]) not in seen
+        # infinity flags belong to the key; an all-zero flag array is the same key as no flag array
+        inf = np.zeros(n, dtype=np.uint8)
+        hz = gl.bases_content_hash(curve, buf)
+        assert gl.bases_content_hash(curve, buf, inf) == hz
+        inf[n // 3] = 1
+        assert gl.bases_content_hash(curve, buf, inf) != hz
+    assert gl.bases_content_hash("mnt4753_g1", np.zeros((4, 24), np.uint64)) != gl.bases_content_hash("mnt6753_g1", np.zeros((4, 24), np.uint64))
+    st = gl.key_cache_stats()
+    assert set(st) == {"entries", "bytes", "hits", "misses", "evictions", "tables_built"}
+    gl.key_cache_config(1 << 30, 0)
+    gl.key_cache_clear()
+    gl.key_cache_config()
+
+
 def test_compute_fails_loudly_without_gpu(gl):
     import torch
     if torch.cuda.is_available():
@@ -62,6 +104,8 @@ def test_compute_fails_loudly_without_gpu(gl):
         gl.VariableBaseMSM.multi_scalar_mul("mnt4753_g1", np.zeros((1, 24), np.uint64), np.zeros((1, 12), np.uint64))
     with pytest.raises(gl.GingerHipError):
         gl.EvaluationDomain("mnt4753_fr", 4).fft(np.zeros((4, 12), np.uint64))
+    with pytest.raises(gl.GingerHipError):
+        gl.msm_cached("mnt4753_g1", np.zeros((1, 24), np.uint64), np.zeros((1, 12), np.uint64))
 
 
 def test_long_branch_guard_rules():

@@ -40,7 +40,30 @@ def _worker(rank, world, port, curve, n, ret):
     total_c = cd.allgather_fold(curve, partial)
     xy_c, inf_c = gl.proj_to_affine(curve, total_c)
     c_ok = cd.world_seen == world and inf_c == is_inf and bool((xy_c == xy).all())
+    # the callback transport says so: no RCCL rank took part
+    c_ok = c_ok and cd.rccl_ranks == 0
+    # a pipelined batch's results in ONE exchange: three partial sums (the shard, the shard's first half, infinity) -> three totals
+    mid = lo + (hi - lo) // 2
+    p_half = S.oracle_msm(curve, b[lo:mid], inf[lo:mid], s[lo:mid], 2)
+    zero = np.zeros_like(partial)
+    zero[12 * C.deg] = 1
+    tot3 = cd.allgather_fold_batch(curve, [partial, p_half, zero])
+    xy0, inf0 = gl.proj_to_affine(curve, tot3[0])
+    c_ok = c_ok and inf0 == is_inf and bool((xy0 == xy).all())
+    halves = [distmod.shard_bounds(n, r, world) for r in range(world)]
+    idx = np.concatenate([np.arange(l, l + (h - l) // 2) for l, h in halves])
+    exp_h = S.oracle_affine(curve, S.oracle_msm(curve, b[idx], inf[idx], s[idx], 2))
+    xy1, inf1 = gl.proj_to_affine(curve, tot3[1])
+    c_ok = c_ok and inf1 == exp_h[1] and bool((xy1 == exp_h[0]).all())
+    c_ok = c_ok and gl.proj_to_affine(curve, tot3[2])[1]           # infinity + infinity
     cd.shutdown()
+    # gh_shutdown tears a communicator down as well (and a second shutdown is harmless)
+    cd2 = distmod.CDist(gl, rank, world, transport="callback", allgather=distmod.gloo_allgather_bytes(dist))
+    gl.shutdown()
+    import ctypes
+    rr = ctypes.c_int(-1)
+    gl.load_library().gh_dist_transport(ctypes.byref(rr), None, None, 0)
+    c_ok = c_ok and rr.value == 0 and gl.load_library().gh_dist_info(None, None) != 0
     full = S.oracle_msm(curve, b, inf, s, 2)
     exy, einf = S.oracle_affine(curve, full)
     ok = c_ok and (is_inf == einf) and bool((xy == exy).all())

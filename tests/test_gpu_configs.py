@@ -94,6 +94,59 @@ def test_cfg3_mnt4_g1_2p24(gpu):
         gpu.dev_trim()
 
 
+# ------------------------------------------------------------------------------ full sizes against a closed form
+def chain_key(gl, curve, n, seed):
+    """n distinct resident bases P_0 + i H (gh_bases_generate_chain, the bench's key) and the two points as pyref values"""
+    C = pyref.CURVES[curve]
+    rng = pyref.Rng(seed)
+    P0, H = C.mul(rng.next_u64() | 1, C.G), C.mul(rng.next_u64() | 1, C.G)
+    xy, _ = S.bases_array(C, [P0, H])
+    return gl.ResidentBases.chain(curve, xy[0], xy[1], n), P0, H
+
+
+def expect_affine(curve, P):
+    xy, inf = S.affine_abi_of_point(pyref.CURVES[curve], P)
+    return inf, xy.tobytes()
+
+
+@pytest.mark.parametrize("curve,log_n,with_table", [("mnt4753_g1", 20, True), ("mnt4753_g1", 24, True), ("mnt6753_g1", 22, True),
+                                                    ("mnt6753_g1", 19, True), ("mnt4753_g2", 20, True), ("mnt6753_g2", 19, True),
+                                                    ("mnt6753_g2", 22, False)])
+def test_full_size_msm_against_closed_form(gpu, curve, log_n, with_table):
+    """Every BASELINE size with an answer that no MSM code path produced: on a chain key P_i = P_0 + i H
+    sum s_i P_i = (sum s_i) P_0 + (sum i s_i) H -- two scalar multiplications in Python integers (the reference's own test
+    is Pippenger == naive sum, variable_base.rs:102-151).  Per-window path, shift table, a pipelined batch with a ragged
+    second length, and the first few bases of the device-generated chain against P_0 + i H itself."""
+    C = pyref.CURVES[curve]
+    n = 1 << log_n
+    rb, P0, H = chain_key(gpu, curve, n, 1000 + log_n)
+    s = S.random_scalars_np(n, seed=600 + log_n, below=C.order)
+    s[5] = 0
+    s[6, :] = 0
+    s[6, 0] = 1
+    s[7] = np.array(pyref.int_to_limbs(C.order - 1), dtype=np.uint64)
+    m = n - 12345
+    exp = expect_affine(curve, S.chain_msm_closed_form(C, P0, H, s))
+    exp_m = expect_affine(curve, S.chain_msm_closed_form(C, P0, H, s[:m]))
+    ds = gpu.DeviceBuffer(s.nbytes).upload(s)
+    try:
+        head = rb.download(0, 3)
+        want = S.bases_array(C, [P0, C.add(P0, H), C.add(C.add(P0, H), H)])[0]
+        assert (head == want).all()
+        tail = rb.download(n - 1, 1)
+        assert (tail == S.bases_array(C, [C.add(P0, C.mul(n - 1, H))])[0]).all()
+        assert affine(gpu, curve, rb.msm_dev(ds, n)) == exp                      # per-window path
+        if with_table:
+            rb.precompute(0)
+            assert affine(gpu, curve, rb.msm_dev(ds, n)) == exp
+        outs = gpu.msm_batch_dev([(rb, ds, n), (rb, ds, m), (rb, ds, n)])
+        assert [affine(gpu, curve, o) for o in outs] == [exp, exp_m, exp]
+    finally:
+        ds.free()
+        rb.free()
+        gpu.dev_trim()
+
+
 # ------------------------------------------------------------------------------ config 4 shapes
 @pytest.mark.parametrize("curve,log_n,pool_n,with_table", [("mnt6753_g1", 19, 4096, True), ("mnt6753_g1", 22, 4096, True),
                                                           ("mnt6753_g2", 19, 512, True), ("mnt6753_g2", 22, 512, False),

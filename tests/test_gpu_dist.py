@@ -33,6 +33,18 @@ def test_rccl_single_rank_exchange(gpu):
             us = ctypes.c_double()
             gpu._check(lib.gh_partials_allgather_fold(gpu.CURVES[curve], gpu._ptr(part), gpu._ptr(out), ctypes.byref(us)))
             assert S.affine_of_xyz(C, out) == P and us.value > 0
+            # three partial sums in one exchange
+            Q = S.chain_points(C, 3, pyref.Rng(4))
+            parts = np.stack([S.proj_array(C, q) for q in Q])
+            outs = np.zeros_like(parts)
+            gpu._check(lib.gh_partials_allgather_fold_batch(gpu.CURVES[curve], gpu._ptr(parts), 3, gpu._ptr(outs), ctypes.byref(us)))
+            assert [S.affine_of_xyz(C, o) for o in outs] == Q
+        # the transport reports itself: one RCCL rank, a version, and the file the symbols came from
+        rr, rv = ctypes.c_int(), ctypes.c_int()
+        path = ctypes.create_string_buffer(512)
+        gpu._check(lib.gh_dist_transport(ctypes.byref(rr), ctypes.byref(rv), path, 512))
+        assert rr.value == 1 and rv.value > 20000 and b"librccl" in path.value
+        print("RCCL in use:", rv.value, path.value.decode())
     finally:
         lib.gh_dist_shutdown()
     assert lib.gh_dist_info(None, None) != 0

@@ -591,3 +591,55 @@ def test_msm_batch_argument_errors(gpu):
     exp = S.oracle_msm("mnt4753_g1", b1, None, s, 4)
     assert affine_eq(gpu, "mnt4753_g1", gpu.msm_batch_dev([(r1, d, 8)])[0], exp)
     d.free(); r1.free(); r2.free()
+
+
+def test_msm_cached_is_a_pure_function_of_its_arguments(gpu):
+    """gh_msm_cached: two different base sets through ONE host buffer (same address, length, first and last base -- what the
+    round-2 Rust shim keyed on) give two different sums, each equal to the oracle's; repeats are hits (scalars only), the
+    shift table appears at the second sighting, and a small budget evicts the least recently used key."""
+    curve = "mnt4753_g1"
+    C = pyref.CURVES[curve]
+    n = 1 << 13
+    pts = S.chain_points(C, n, pyref.Rng(21))
+    buf, _ = S.bases_array(C, pts)
+    other, _ = S.bases_array(C, S.chain_points(C, n, pyref.Rng(22)))
+    s1 = S.random_scalars_np(n, seed=71, below=C.order)
+    s2 = S.random_scalars_np(n, seed=72, below=C.order)
+    gpu.key_cache_clear()
+    gpu.key_cache_config(64 << 30, 2)
+    base = gpu.key_cache_stats()
+
+    def aff(x):
+        xy, inf = gpu.proj_to_affine(curve, x)
+        return inf, xy.tobytes()
+
+    def oaff(b, s):
+        xy, inf = S.oracle_affine(curve, S.oracle_msm(curve, b, None, s, 16))
+        return inf, xy.tobytes()
+
+    exp_a1, exp_a2 = oaff(buf, s1), oaff(buf, s2)
+    assert aff(gpu.msm_cached(curve, buf, s1)) == exp_a1                       # miss: upload
+    assert gpu.msm_last_timing()["num_windows"] == 752 // gpu.msm_last_timing()["window_bits"] + 1
+    assert aff(gpu.msm_cached(curve, buf, s2)) == exp_a2                       # hit: second sighting builds the table
+    st = gpu.key_cache_stats()
+    assert (st["misses"] - base["misses"], st["hits"] - base["hits"], st["tables_built"] - base["tables_built"], st["entries"]) == (1, 1, 1, 1)
+    addr = buf.ctypes.data
+    buf[1:n - 1] = other[1:n - 1]                                             # same buffer, same ends, other interior
+    assert buf.ctypes.data == addr
+    exp_b1 = oaff(buf, s1)
+    assert exp_b1 != exp_a1
+    assert aff(gpu.msm_cached(curve, buf, s1)) == exp_b1                       # NOT the stale key's sum
+    st = gpu.key_cache_stats()
+    assert st["misses"] - base["misses"] == 2 and st["entries"] == 2
+    # ragged lengths: the key is the first min(n_bases, n_scalars) bases
+    m = n - 777
+    assert aff(gpu.msm_cached(curve, buf, s1[:m])) == oaff(buf[:m], s1[:m])
+    # a budget below two keys: the least recently used one goes
+    before = gpu.key_cache_stats()
+    gpu.key_cache_config(int(n * 208 * 1.5), 0)
+    st = gpu.key_cache_stats()
+    assert st["entries"] == 1 and st["evictions"] > before["evictions"]
+    assert aff(gpu.msm_cached(curve, buf, s2)) == oaff(buf, s2)
+    gpu.key_cache_config()
+    gpu.key_cache_clear()
+    assert gpu.key_cache_stats()["entries"] == 0

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from bench import kernels_sha
 
-ACC = ("msm_accumulate_kernel", "msm_accumulate_split_kernel", "aff_round_kernel", "aff_desc_kernel", "msm_heavy_combine_kernel")
+ACC = ("msm_accumulate_kernel", "msm_accumulate_xyzz_kernel", "msm_accumulate_split_kernel", "aff_round_kernel", "aff_desc_kernel", "msm_heavy_combine_kernel")
 
 
 def per_dispatch(path, counter):
