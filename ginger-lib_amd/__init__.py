@@ -39,7 +39,7 @@ ABI_SYMBOLS = [
     "gh_lagrange_coefficients", "gh_lagrange_coefficients_dev",
     "gh_dev_alloc", "gh_dev_free", "gh_dev_upload", "gh_dev_download", "gh_dev_sync", "gh_dev_trim",
     "gh_proj_add", "gh_proj_mul", "gh_proj_neg", "gh_proj_to_affine",
-    "gh_fixed_base_window", "gh_fixed_base_table", "gh_fixed_base_msm", "gh_fixed_base_free",
+    "gh_fixed_base_window", "gh_fixed_base_table", "gh_fixed_base_msm", "gh_fixed_base_msm_affine", "gh_fixed_base_free",
 ]
 # include/ginger_hip_dist.h
 DIST_SYMBOLS = ["gh_dist_unique_id", "gh_dist_probe_rccl", "gh_dist_init_rccl", "gh_dist_init_custom", "gh_dist_info", "gh_dist_transport",
@@ -131,6 +131,7 @@ def load_library():
     lib.gh_fixed_base_window.argtypes = [sz]
     lib.gh_fixed_base_table.argtypes = [ci, vp, sz, ci, ctypes.POINTER(vp)]
     lib.gh_fixed_base_msm.argtypes = [vp, vp, sz, vp]
+    lib.gh_fixed_base_msm_affine.argtypes = [vp, vp, sz, vp, vp, ci]
     lib.gh_fixed_base_free.argtypes = [vp]
     lib.gh_dist_unique_id.argtypes = [vp]
     lib.gh_dist_init_rccl.argtypes = [vp, ci, ci]
@@ -367,6 +368,16 @@ class FixedBaseMSM:
         out = np.zeros((n, 36 * CURVE_DEG[self.curve]), dtype=np.uint64)
         _check(load_library().gh_fixed_base_msm(self.handle, _ptr(s), n, _ptr(out)))
         return out
+
+    def multi_scalar_mul_affine(self, scalars, canonical=False):
+        """multi_scalar_mul followed by batch_normalization + into_affine on the device (generator.rs:247-335):
+        (n x 24*deg u64 x || y rows, n infinity flags); canonical=True gives the integers GroupAffine::write serialises"""
+        s = _u64(scalars, 12)
+        n = s.size // 12
+        xy = np.zeros((n, 24 * CURVE_DEG[self.curve]), dtype=np.uint64)
+        inf = np.zeros(n, dtype=np.uint8)
+        _check(load_library().gh_fixed_base_msm_affine(self.handle, _ptr(s), n, _ptr(xy), _ptr(inf), 1 if canonical else 0))
+        return xy, inf
 
     def free(self):
         if self.handle:

@@ -62,17 +62,71 @@ fixed_msm_kernel(const Aff<C>* __restrict__ table, int window, uint32_t outerc, 
     Proj<C> acc = proj_zero<C>();
     for (uint32_t outer = 0; outer < outerc; outer++) {
         const uint32_t bit = outer * (uint32_t)window;
+        // windowed_mul (:45-66) reads `window` bits per row, but none at or above MODULUS_BITS = 753 (both scalar fields), and a
+        // digit of the last row at or beyond last_in_window = 2^(scalar_size - (outerc - 1) window) finds the zero the table was
+        // initialised with (:22-33) -- which only happens for scalar_size < 753 with a scalar that has higher bits set
         uint32_t nb = (uint32_t)window;
-        if (bit + nb > scalar_size) nb = scalar_size - bit;            // bits at and above MODULUS_BITS are not read (:56)
+        if (bit >= 753u) continue;
+        if (bit + nb > 753u) nb = 753u - bit;
         const uint32_t wi = bit >> 5, sh = bit & 31;
         const uint64_t two = (uint64_t)s[wi] | ((uint64_t)s[wi + 1] << 32);
         const uint32_t d = (uint32_t)(two >> sh) & ((1u << nb) - 1u);
         if (d == 0) continue;
+        if (outer == outerc - 1 && d >= (1u << (scalar_size - (outerc - 1) * (uint32_t)window))) continue;
         const Aff<C> q = ld_words(table + ((size_t)outer << window) + d);
         if (F::comp(q.x, 0).l[0] == AFF_MARK) continue;
         acc = proj_madd_call<C>(acc, q);
     }
     st_words(out + i, acc);
+}
+
+// batch_normalization + into_affine of a vector of projective points (short_weierstrass_projective.rs:402-442, :663-678; the
+// parameter generator does exactly this to every query: generator.rs:318-335), written in the C ABI's affine layout:
+// n x (x || y) coefficients, either Montgomery 2^768 (the in-memory form) or -- canonical != 0 -- plain integers (what
+// GroupAffine::write serialises, :185-192), plus the infinity flags; infinity is GroupAffine::zero() = (0, 1, true).
+// One thread per run of NORM_RUN points: prefix products of the non-zero Z, ONE inversion, backward sweep (Montgomery's trick).
+constexpr int NORM_RUN = 32;
+template <class C>
+__global__ void __launch_bounds__(64)
+fixed_normalize_kernel(const Proj<C>* __restrict__ in, size_t n, int canonical, uint32_t* __restrict__ out_xy, uint8_t* __restrict__ out_inf,
+                       typename C::FC::T* __restrict__ zp) {
+    typedef typename C::FC F;
+    typedef typename C::PF PF;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t i0 = t * NORM_RUN;
+    if (i0 >= n) return;
+    const int cnt = (int)(n - i0 < (size_t)NORM_RUN ? n - i0 : (size_t)NORM_RUN);
+    typename F::T run = F::one();
+    for (int j = 0; j < cnt; j++) {
+        const typename F::T z = ld_words(&in[i0 + j].z);
+        st_words(zp + i0 + j, run);                      // product of the non-zero Z before j
+        if (!F::is_zero(z)) run = F::mul(run, z);
+    }
+    typename F::T inv = DevInv<F>::inv(run);
+    Fp plain_one = fp_zero();
+    plain_one.l[0] = 1;
+    auto put = [&](uint32_t* w, const typename F::T& v) {
+        for (int d = 0; d < F::DEG; d++) {
+            const Fp& c = F::comp(v, d);
+            if (canonical) fp_pack(w + 24 * d, fp_mul_call<PF>(c, plain_one));   // internal Montgomery (x 2^754) -> the integer itself
+            else fp_to_abi<PF>(w + 24 * d, c);
+        }
+    };
+    for (int j = cnt - 1; j >= 0; j--) {
+        const Proj<C> p = ld_words(in + i0 + j);
+        uint32_t* w = out_xy + (i0 + j) * (size_t)(48 * F::DEG);
+        if (F::is_zero(p.z)) {
+            put(w, F::zero());
+            put(w + 24 * F::DEG, F::one());
+            out_inf[i0 + j] = 1;
+            continue;
+        }
+        const typename F::T zi = F::mul(inv, ld_words(zp + i0 + j));      // 1 / Z_j
+        inv = F::mul(inv, p.z);
+        put(w, F::mul(p.x, zi));
+        put(w + 24 * F::DEG, F::mul(p.y, zi));
+        out_inf[i0 + j] = 0;
+    }
 }
 
 // Synthetic key for benchmarks and full-size tests: n DISTINCT points P_i = P_0 + i H along an addition
@@ -204,6 +258,31 @@ template <class C> int run_fixed(const FixedTable* t, const uint64_t* scalars, s
     return GH_OK;
 }
 
+// FixedBaseMSM::multi_scalar_mul + batch_normalization + into_affine, all on the device (generator.rs:247-335 per query)
+template <class C> int run_fixed_affine(const FixedTable* t, const uint64_t* scalars, size_t n, uint64_t* out_xy, uint8_t* out_inf, int canonical) {
+    typedef typename C::F F;
+    typedef typename C::FC::T FT;
+    if (n == 0) return GH_OK;
+    void *d_s = nullptr, *d_o = nullptr, *d_xy = nullptr, *d_inf = nullptr, *d_zp = nullptr;
+    int rc = pool_get("fixed_scalars", n * 96, &d_s);
+    if (!rc) rc = pool_get("fixed_out", n * sizeof(Proj<C>), &d_o);
+    if (!rc) rc = pool_get("fixed_xy", n * (size_t)(192 * F::DEG), &d_xy);
+    if (!rc) rc = pool_get("fixed_inf", n, &d_inf);
+    if (!rc) rc = pool_get("fixed_zp", n * sizeof(FT), &d_zp);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(d_s, scalars, n * 96, hipMemcpyHostToDevice, g.stream));
+    hipLaunchKernelGGL((fixed_msm_kernel<C>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, g.stream, (const Aff<C>*)t->d_table,
+                       t->window, t->outerc, t->scalar_size, (const uint32_t*)d_s, n, (Proj<C>*)d_o);
+    const size_t threads = (n + NORM_RUN - 1) / NORM_RUN;
+    hipLaunchKernelGGL((fixed_normalize_kernel<C>), dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, g.stream, (const Proj<C>*)d_o, n, canonical,
+                       (uint32_t*)d_xy, (uint8_t*)d_inf, (FT*)d_zp);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out_xy, d_xy, n * (size_t)(192 * F::DEG), hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipMemcpyAsync(out_inf, d_inf, n, hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    return GH_OK;
+}
+
 template <class C> int chain_bases(const uint64_t* p0_xy, const uint64_t* h_xy, size_t n, BasesBase** out) {
     typedef typename C::F F;
     typedef typename C::FC::T FT;
@@ -271,6 +350,16 @@ int fixed_run(const FixedTable* t, const uint64_t* scalars, size_t n, uint64_t* 
     return GH_E_BAD_ARG;
 }
 
+int fixed_run_affine(const FixedTable* t, const uint64_t* scalars, size_t n, uint64_t* out_xy, uint8_t* out_inf, int canonical) {
+    switch (t->curve) {
+        case GH_MNT4753_G1: return run_fixed_affine<Mnt4G1>(t, scalars, n, out_xy, out_inf, canonical);
+        case GH_MNT4753_G2: return run_fixed_affine<Mnt4G2>(t, scalars, n, out_xy, out_inf, canonical);
+        case GH_MNT6753_G1: return run_fixed_affine<Mnt6G1>(t, scalars, n, out_xy, out_inf, canonical);
+        case GH_MNT6753_G2: return run_fixed_affine<Mnt6G2>(t, scalars, n, out_xy, out_inf, canonical);
+    }
+    return GH_E_BAD_ARG;
+}
+
 }  // namespace gh_rt
 
 using namespace gh_rt;
@@ -304,6 +393,16 @@ int gh_fixed_base_msm(gh_fixed_table_t table, const uint64_t* scalars, size_t n,
     int rc = ensure_init();
     if (rc) return rc;
     return fixed_run(t, scalars, n, out_xyz);
+}
+
+int gh_fixed_base_msm_affine(gh_fixed_table_t table, const uint64_t* scalars, size_t n, uint64_t* out_xy, uint8_t* out_inf, int canonical) {
+    std::lock_guard<std::mutex> lk(api_mutex());
+    FixedTable* t = reinterpret_cast<FixedTable*>(table);
+    if (!t || t->magic != 0x67684654u) { g_err = "bad fixed-base table handle"; return GH_E_BAD_HANDLE; }
+    if (n && (!scalars || !out_xy || !out_inf)) { g_err = "null argument"; return GH_E_BAD_ARG; }
+    int rc = ensure_init();
+    if (rc) return rc;
+    return fixed_run_affine(t, scalars, n, out_xy, out_inf, canonical);
 }
 
 int gh_bases_generate_chain(gh_curve_t curve, const uint64_t* p0_xy, const uint64_t* step_xy, size_t n, gh_bases_t* out_handle) {

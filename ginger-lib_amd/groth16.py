@@ -89,6 +89,133 @@ def benchmark_circuit_rows(pairing, num_constraints):
     return num_inputs, inputs + aux, A, B, C
 
 
+def benchmark_circuit_lcs(num_constraints):
+    """The same circuit as linear combinations, the form the key generator consumes (KeypairAssembly: at / bt / ct rows of
+    (coefficient, index) with inputs first, generator.rs:28-110): constraints.rs:20-92 statement by statement.
+    -> (num_inputs, num_aux, at, bt, ct); index 0 is the constant one."""
+    num_inputs = 3
+    var = [1, 2]                                             # v_0 = a (input 1), v_1 = b (input 2); v_(k+2) = aux k
+    at, bt, ct = [], [], []
+    n_aux = 0
+    recorded = [1, 1]                                        # (a, a): sic, :31-36
+    for i in range(num_constraints - 1):
+        c_var = num_inputs + n_aux
+        n_aux += 1
+        a_var, b_var = var[-2], var[-1]
+        if i % 2 != 0:
+            at.append([(1, a_var)]); bt.append([(1, b_var)]); ct.append([(1, c_var)])
+        else:
+            at.append([(1, a_var), (1, b_var)]); bt.append([(1, 0)]); ct.append([(1, c_var)])
+        var = [b_var, c_var]
+        recorded.append(c_var)
+    c_var = num_inputs + n_aux
+    n_aux += 1
+    lc = [(1, v) for v in recorded]
+    at.append(lc); bt.append(list(lc)); ct.append([(1, c_var)])
+    return num_inputs, n_aux, at, bt, ct
+
+
+def _ints_from_mont_rows(rows, modulus):
+    rinv = pow(1 << 768, -1, modulus)
+    raw = np.ascontiguousarray(rows, dtype=np.uint64).tobytes()
+    return [int.from_bytes(raw[96 * i:96 * i + 96], "little") * rinv % modulus for i in range(len(raw) // 96)]
+
+
+def _canon_rows_fast(vals):
+    return np.frombuffer(b"".join(int(v).to_bytes(96, "little") for v in vals), dtype=np.uint64).reshape(-1, 12) if len(vals) else np.zeros((0, 12), np.uint64)
+
+
+def generate_parameters(gl, pairing, lcs, alpha, beta, gamma, delta, t, g1_xyz, g2_xyz, vk_pairing_bytes=None):
+    """generate_parameters (proof-systems/src/groth16/generator.rs:146-335) above the C ABI, for a constraint system given as
+    linear combinations; the toxic waste, the evaluation point t (sample_element_outside_domain, :181) and the two
+    generators (:225-226, `rand`) are arguments instead of RNG draws.  Returns (Parameters::write bytes, info).
+      * Lagrange coefficients at t on the device (gh_lagrange_coefficients = evaluate_all_lagrange_coefficients, domain.rs:183-219);
+      * instance_map_with_evaluation (r1cs_to_qap.rs:14-69): host integers, as in the reference;
+      * the five queries and gamma_abc_g1: FixedBaseMSM on the device with the reference's window rule (:233-311), followed
+        by batch_normalization + into_affine (:318-335) -- gh_fixed_base_msm_affine, straight into the serialised form;
+      * vk.alpha_g1_beta_g2 is a pairing value (:313): pairings are out of scope, the prover never reads it -- filler bytes
+        unless the caller supplies them."""
+    r = _MODULUS[pairing]
+    field = "mnt4753_fr" if pairing == "mnt4753" else "mnt6753_fr"
+    g1c, g2c = pairing + "_g1", pairing + "_g2"
+    num_inputs, num_aux, at, bt, ct = lcs
+    n_con = len(at)
+    size = 1
+    while size < n_con + (num_inputs - 1) + 1:
+        size <<= 1
+    log_n = size.bit_length() - 1
+    zt = (pow(t, size, r) - 1) % r                                               # evaluate_vanishing_polynomial
+    tau = _mont_rows([t], r)[0]
+    u_rows = np.zeros((size, 12), dtype=np.uint64)
+    gl._check(gl.load_library().gh_lagrange_coefficients(gl.FIELDS[field], log_n, gl._ptr(tau), gl._ptr(u_rows)))
+    u = _ints_from_mont_rows(u_rows, r)
+    nv = (num_inputs - 1) + num_aux
+    a, b, c = [0] * (nv + 1), [0] * (nv + 1), [0] * (nv + 1)
+    for i in range(num_inputs):
+        a[i] = u[n_con + i]
+    for rows, acc in ((at, a), (bt, b), (ct, c)):
+        for i, row in enumerate(rows):
+            ui = u[i]
+            for cf, ix in row:
+                acc[ix] = (acc[ix] + (ui if cf == 1 else ui * cf)) % r
+    non_zero_a = sum(1 for v in a[:nv] if v)
+    non_zero_b = sum(1 for v in b[:nv] if v)
+    gi, di = pow(gamma, -1, r), pow(delta, -1, r)
+    comb = [(beta * x + alpha * y + z) % r for x, y, z in zip(a, b, c)]
+    gamma_abc = [v * gi % r for v in comb[:num_inputs]]
+    l = [v * di % r for v in comb]
+    hs, cur = [], zt * di % r
+    for _ in range(size - 1):
+        hs.append(cur)
+        cur = cur * t % r
+    FB = gl.FixedBaseMSM
+    g1_window = FB.get_mul_window_size(non_zero_a + non_zero_b + nv + size + 1)
+    g2_window = FB.get_mul_window_size(non_zero_b)
+    stats = {"fixed_base_scalars": 0, "fixed_base_s": 0.0}
+
+    def wire_rows(table, deg, vals):
+        import time
+        t0 = time.perf_counter()
+        xy, inf = table.multi_scalar_mul_affine(_canon_rows_fast(vals), canonical=True)
+        stats["fixed_base_s"] += time.perf_counter() - t0
+        stats["fixed_base_scalars"] += len(vals)
+        rec = np.empty((len(vals), 192 * deg + 1), dtype=np.uint8)
+        rec[:, :192 * deg] = xy.view(np.uint8).reshape(len(vals), 192 * deg)
+        rec[:, 192 * deg] = inf
+        return rec.tobytes()
+
+    def wire_point(curve, deg, g_xyz, k):
+        xy, inf = gl.proj_to_affine(curve, gl.proj_mul(curve, g_xyz, _canon_rows([k])[0]))
+        return affine_to_wire(pairing, "g1" if deg == 1 else "g2", xy, inf)
+
+    deg2 = _G2_DEG[pairing]
+    t1 = FB(g1c, g1_xyz, 753, g1_window)
+    try:
+        a_q = wire_rows(t1, 1, a)
+        b1_q = wire_rows(t1, 1, b)
+        h_q = wire_rows(t1, 1, hs)
+        l_q = wire_rows(t1, 1, l)[193 * num_inputs:]                             # l_query[num_inputs..]  (:298)
+        abc_q = wire_rows(t1, 1, gamma_abc)
+    finally:
+        t1.free()
+    t2 = FB(g2c, g2_xyz, 753, g2_window)
+    try:
+        b2_q = wire_rows(t2, deg2, b)
+    finally:
+        t2.free()
+    blob = bytearray()
+    blob += vk_pairing_bytes if vk_pairing_bytes is not None else bytes((i * 37 + 5) & 0xFF for i in range(_FQK_BYTES[pairing]))
+    blob += wire_point(g2c, deg2, g2_xyz, gamma) + wire_point(g2c, deg2, g2_xyz, delta)
+    blob += struct.pack(">I", num_inputs) + abc_q
+    blob += wire_point(g1c, 1, g1_xyz, alpha) + wire_point(g1c, 1, g1_xyz, beta) + wire_point(g2c, deg2, g2_xyz, beta)
+    blob += wire_point(g1c, 1, g1_xyz, delta) + wire_point(g2c, deg2, g2_xyz, delta)
+    for q, rec in ((a_q, 193), (b1_q, 193), (b2_q, 192 * deg2 + 1), (h_q, 193), (l_q, 193)):
+        blob += struct.pack(">I", len(q) // rec) + q
+    info = {"num_inputs": num_inputs, "log_n": log_n, "qap": (a, b, c, l, zt), "g1_window": g1_window, "g2_window": g2_window,
+            "non_zero": (non_zero_a, non_zero_b), "fixed_base": stats}
+    return bytes(blob), info
+
+
 def _mont_rows(vals, modulus):
     """Python integers -> n x 12 u64 Montgomery rows (x * 2^768 mod p), the in-memory form of Fp768 (fp_768.rs:24-30)"""
     R = (1 << 768) % modulus

@@ -166,6 +166,11 @@ typedef struct gh_fixed_table* gh_fixed_table_t;
 int gh_fixed_base_window(size_t num_scalars);
 int gh_fixed_base_table(gh_curve_t curve, const uint64_t* g_xyz, size_t scalar_size, int window, gh_fixed_table_t* out_table);
 int gh_fixed_base_msm(gh_fixed_table_t table, const uint64_t* scalars, size_t n, uint64_t* out_xyz);
+/* The same followed by batch_normalization + into_affine on the device (what the parameter generator does to every query:
+ * proof-systems/src/groth16/generator.rs:247-335; short_weierstrass_projective.rs:402-442, :663-678): n affine points as
+ * x || y coefficients -- Montgomery 2^768 limbs, or with canonical != 0 the plain integers GroupAffine::write serialises
+ * (:185-192) -- and n infinity flags (infinity = GroupAffine::zero() = (0, 1, true)).                                    */
+int gh_fixed_base_msm_affine(gh_fixed_table_t table, const uint64_t* scalars, size_t n, uint64_t* out_xy, uint8_t* out_inf, int canonical);
 int gh_fixed_base_free(gh_fixed_table_t table);
 
 /* Window size override for sweeps (0 = automatic).  Affects subsequent MSM calls. */

@@ -438,3 +438,78 @@ def test_cfg5_benchmark_circuit_2p20_end_to_end(gpu):
             key.free()
     assert proofs[0] == proofs[1] and len(proofs[0]) == 193 + 385 + 193
     gpu.dev_trim()
+
+
+# ------------------------------------------------------------------------------ config 5: the key itself made on the device
+@pytest.mark.parametrize("pairing,n_con", [("mnt4753", 61), ("mnt6753", 29)])
+def test_cfg5_generator_on_device_equals_first_principles_generator(gpu, pairing, n_con):
+    """groth16.generate_parameters (generator.rs:146-335 above the C ABI: Lagrange coefficients, FixedBaseMSM, batch
+    normalisation on the device) emits byte for byte the Parameters::write stream of tests/groth16_ref.py's generator, which
+    is pinned by the proof-in-the-exponent test (tests/test_groth16_ref.py) -- same toxic waste, same generators."""
+    groth16 = importlib.import_module("ginger_lib_amd.groth16")
+    import groth16_ref as G
+    C1, C2 = pyref.CURVES[pairing + "_g1"], pyref.CURVES[pairing + "_g2"]
+    blob_ref, info = G.generate_parameters(pairing, n_con, seed=3)
+    alpha, beta, gamma, delta, t = info["toxic"]
+    g1, g2 = info["generators"]
+    lcs = groth16.benchmark_circuit_lcs(n_con)
+    assert (lcs[0], lcs[2], lcs[3], lcs[4]) == (info["num_inputs"], info["at"], info["bt"], info["ct"])
+    blob, ginfo = groth16.generate_parameters(gpu, pairing, lcs, alpha, beta, gamma, delta, t, S.proj_array(C1, g1), S.proj_array(C2, g2))
+    assert ginfo["qap"][:4] == tuple(info["qap"][:4]) and ginfo["qap"][4] == info["qap"][4]
+    assert blob == blob_ref
+    gpu.dev_trim()
+
+
+def test_cfg5_key_generated_on_device_at_2p20_and_proof_in_closed_form(gpu):
+    """BASELINE config 5 at its own size from reference-format bytes: the proving key of the `Benchmark` circuit with
+    2^20 - 3 constraints (domain 2^20) is GENERATED on the device (gh_lagrange_coefficients + gh_fixed_base_msm_affine, the
+    reference's window rule), serialised as Parameters::write does, parsed back, made resident (gh_bases_upload_wire +
+    shift tables) and used by create_proof; A, B and C are then compared with the Groth16 equations evaluated in the
+    exponent from the toxic waste -- Python integers and two/three textbook scalar multiplications, no MSM involved."""
+    import time
+    groth16 = importlib.import_module("ginger_lib_amd.groth16")
+    import groth16_ref as G
+    pairing = "mnt4753"
+    C1, C2 = pyref.CURVES[pairing + "_g1"], pyref.CURVES[pairing + "_g2"]
+    r = C1.order
+    n_con = (1 << 20) - 3
+    rng = pyref.Rng(2026)
+    alpha, beta, gamma, delta, t, r_, s_ = (rng.field_elem(r) for _ in range(7))
+    g1, g2 = C1.mul(rng.next_u64() | 1, C1.G), C2.mul(rng.next_u64() | 1, C2.G)
+    t0 = time.perf_counter()
+    lcs = groth16.benchmark_circuit_lcs(n_con)
+    blob, info = groth16.generate_parameters(gpu, pairing, lcs, alpha, beta, gamma, delta, t, S.proj_array(C1, g1), S.proj_array(C2, g2))
+    t_gen = time.perf_counter() - t0
+    del lcs
+    assert info["log_n"] == 20
+    fb = info["fixed_base"]
+    print("generate_parameters 2^20: %.1f s, %d fixed-base scalar-muls in %.2f s on the device (%.2f M/s), windows g1 %d g2 %d, %d MB" % (
+        t_gen, fb["fixed_base_scalars"], fb["fixed_base_s"], fb["fixed_base_scalars"] / fb["fixed_base_s"] / 1e6, info["g1_window"], info["g2_window"], len(blob) >> 20))
+    pk = groth16.parse_parameters(pairing, blob)
+    assert len(pk["a_query"]) == 193 * (n_con + 3) and len(pk["h_query"]) == 193 * ((1 << 20) - 1) and len(pk["l_query"]) == 193 * n_con
+    t0 = time.perf_counter()
+    key = groth16.ResidentProvingKey.from_parameters(gpu, pairing, blob, 3)
+    t_load = time.perf_counter() - t0
+    del blob, pk
+    try:
+        rows = groth16.benchmark_circuit_rows(pairing, n_con)
+        t0 = time.perf_counter()
+        proof = key.create_proof(rows, 0, 0, 0, r_, s_)
+        t_proof = time.perf_counter() - t0
+    finally:
+        key.free()
+        gpu.dev_trim()
+    print("key load %.1f s, create_proof %.2f s" % (t_load, t_proof))
+    a, b, c, l, zt = info["qap"]
+    asg = rows[1]
+    assert len(asg) == len(a) == n_con + 3
+    sa = sum(x * y for x, y in zip(asg, a)) % r
+    sb = sum(x * y for x, y in zip(asg, b)) % r
+    sc = sum(x * y for x, y in zip(asg, c)) % r
+    di = pow(delta, -1, r)
+    A_s = (alpha + sa + r_ * delta) % r
+    B_s = (beta + sb + s_ * delta) % r
+    H = (sa * sb - sc) * di % r                                  # h(t) Z(t) / delta with d1 = d2 = d3 = 0 (QAP divisibility)
+    C_s = (sum(asg[i] * l[i] for i in range(3, len(asg))) + H + s_ * A_s + r_ * B_s - r_ * s_ * delta) % r
+    exp = G.wire(C1, C1.mul(A_s, g1)) + G.wire(C2, C2.mul(B_s, g2)) + G.wire(C1, C1.mul(C_s, g1))
+    assert proof == exp

@@ -11,13 +11,13 @@ import support as S
 pytestmark = pytest.mark.gpu
 
 
-def oracle_fixed(curve, g_xyz, window, scal_mont, n, threads=8):
+def oracle_fixed(curve, g_xyz, window, scal_mont, n, threads=8, scalar_size=753):
     C = pyref.CURVES[curve]
     O = S.oracle()
     O.oracle_fixed_base_msm.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t,
                                         ctypes.c_void_p, ctypes.c_int]
     out = np.zeros((n, 36 * C.deg), dtype=np.uint64)
-    w = O.oracle_fixed_base_msm(S.CURVE_ID[curve], S.ptr(g_xyz), 753, window, S.ptr(scal_mont), n, S.ptr(out), threads)
+    w = O.oracle_fixed_base_msm(S.CURVE_ID[curve], S.ptr(g_xyz), scalar_size, window, S.ptr(scal_mont), n, S.ptr(out), threads)
     assert w > 0
     return out, w
 
@@ -54,6 +54,45 @@ def test_fixed_base_msm_vs_oracle(gpu, curve, n):
     out = tab.multi_scalar_mul(canon[:10])
     tab.free()
     assert all(gpu.proj_to_affine(curve, out[i])[1] for i in range(10))
+
+
+@pytest.mark.parametrize("curve", ["mnt4753_g1", "mnt6753_g2"])
+def test_fixed_base_short_scalar_size_and_affine_output(gpu, curve):
+    """(a) scalar_size < MODULUS_BITS with scalars that have higher bits set: windowed_mul (fixed_base.rs:45-66) still reads
+    `window` bits per row below bit 753, and a digit of the last row at or beyond last_in_window meets the zero the table was
+    initialised with (:22-33) -- the device follows that, digit by digit, against the oracle's literal restatement;
+    (b) gh_fixed_base_msm_affine = multi_scalar_mul + batch_normalization + into_affine (generator.rs:247-335): Montgomery rows
+    equal gh_proj_to_affine of every projective output, canonical rows are the same integers out of Montgomery form, and
+    infinity is GroupAffine::zero() = (0, 1, true)."""
+    C = pyref.CURVES[curve]
+    F = S.FIELD_OF["mnt4753_fr" if curve.startswith("mnt4") else "mnt6753_fr"]
+    r = C.order
+    n = 150
+    rng = pyref.Rng(91)
+    ks = [rng.field_elem(r) for _ in range(n)]
+    ks[:6] = [0, 1, 3, 4, (1 << 250) - 1, 1 << 250]
+    canon, mont = S.scalar_array(ks), S.fe_array(F, ks)
+    g_xyz = S.proj_array(C, S.chain_points(C, 1, rng)[0])
+    for scalar_size, window in ((250, 8), (753, 7), (100, 3)):
+        exp, _ = oracle_fixed(curve, g_xyz, window, mont, n, scalar_size=scalar_size)
+        tab = gpu.FixedBaseMSM(curve, g_xyz, scalar_size, window)
+        try:
+            got = tab.multi_scalar_mul(canon)
+            xy_m, inf_m = tab.multi_scalar_mul_affine(canon)
+            xy_c, inf_c = tab.multi_scalar_mul_affine(canon, canonical=True)
+        finally:
+            tab.free()
+        k = C.deg
+        for i in range(n):
+            e_xy, e_inf = S.oracle_affine(curve, exp[i])
+            a_xy, a_inf = gpu.proj_to_affine(curve, got[i])
+            assert a_inf == e_inf and (a_xy == e_xy).all(), (scalar_size, window, i)
+            assert bool(inf_m[i]) == e_inf and bool(inf_c[i]) == e_inf
+            assert (xy_m[i] == e_xy).all(), (scalar_size, window, i)          # infinity: (0, 1) in Montgomery form on both sides
+            want = [C.F.from_mont(pyref.limbs_to_int([int(v) for v in e_xy[12 * c:12 * c + 12]])) for c in range(2 * k)]
+            have = [pyref.limbs_to_int([int(v) for v in xy_c[i][12 * c:12 * c + 12]]) for c in range(2 * k)]
+            assert have == want
+        assert inf_m[0] == 1 and inf_m[1] == 0
 
 
 def test_fixed_base_generator_scale(gpu):
