@@ -138,7 +138,9 @@ inline int precompute_window(size_t n, int deg) {
     // G2: with the affine rounds the accumulation costs 6 tower products per addition instead of 11, while the bucket
     // reduction (2^(c-1) buckets, projective) keeps its price: c = 21 at 2^20 pairs left 26 ms of reduction next to 80 ms
     // of accumulation; c = 19 has a quarter of the buckets for 11 % more additions.
-    if (deg > 1) c = lg <= 19 ? 18 : (lg <= 22 ? 19 : 21);
+    // (round 3, profiles/r03_shard_sweep.txt: MNT6 G2 2^19 c = 19 5.77 M/s vs c = 18 5.63; 2^22 c = 21 7.26 vs c = 19 6.74 -- at 4 M pairs the
+    //  accumulation is long enough to carry the 2^20-bucket reduction)
+    if (deg > 1) c = lg <= 18 ? 18 : (lg <= 21 ? 19 : 21);
     else if (lg <= 17) c = 18;
     else if (lg == 18) c = 20;
     else if (lg <= 22) c = 21;

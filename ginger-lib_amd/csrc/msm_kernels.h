@@ -1216,9 +1216,10 @@ template <class C> __device__ __forceinline__ Proj<C> proj_add_raw(const Proj<C>
     GH_RFENCE();
     o.z = F::mul(vvv, z1z2);                               // z1z2 dead
     GH_RFENCE();
-    typename F::T t1 = F::mul(F::sub(r, a), u);            // r, a, u dead
-    GH_RFENCE();
-    o.y = F::sub(t1, F::mul(vvv, y1z2));
+    // Y3 = (r - a) u - vvv y1z2 as ONE dual product on a single accumulator chain (fp_mul2s, as in the XYZZ accumulation: one
+    // Montgomery reduction of fourteen saved; the kernel's scratch frame is unchanged by it: 736 -> 640 B per lane in the
+    // 512-register build, 1760 -> 1792 B in the 256-register one).  The towers keep two products.
+    o.y = F::mul_sub_mul1(F::sub(r, a), u, vvv, y1z2);
 #undef GH_RFENCE
     return o;
 }

@@ -130,3 +130,11 @@ def test_long_branch_guard_rules():
     if os.path.exists(lib):
         found, n_funcs, n_kernels, _ = clb.check(lib)
         assert found == [] and n_kernels > 50 and n_funcs > n_kernels
+    # a file without gfx950 code objects is "nothing checked" (status 2), not "0 findings" (status 0)
+    import subprocess
+    import sys
+    import tempfile
+    with tempfile.NamedTemporaryFile(suffix=".so") as f:
+        f.write(b"\x7fELF not a fat binary")
+        f.flush()
+        assert subprocess.call([sys.executable, os.path.join(ROOT, "tools", "check_long_branches.py"), f.name], stdout=subprocess.DEVNULL) == 2

@@ -11,7 +11,10 @@ Rules enforced (s_getpc_b64 is also the ordinary call sequence, so only the regi
     1. a device function that is not a kernel may hold `s_getpc_b64 s[30:31]` only after it saved s30;
     2. a LEAF device function (no s_swappc_b64) may not exceed MAX_LEAF_BYTES, the size at which relaxation starts.
 
-Usage: python3 tools/check_long_branches.py [path/to/libginger_hip.so]     exit status 1 on a finding.
+Usage: python3 tools/check_long_branches.py [path/to/libginger_hip.so]
+Exit status: 0 clean; 1 a finding (the build renames the library to .rejected); 2 the check could not run -- llvm-objdump /
+llvm-readelf missing, or no gfx950 code object / no kernel found in the library (another bundle format): a guard that looked
+at nothing must not report "0 findings", and a missing tool must not reject a good library.
 Reads the gfx950 code objects out of the library's .hip_fatbin section (clang offload bundles) and disassembles
 them with llvm-objdump; `__graft_entry__.build()` runs it after linking."""
 import os
@@ -21,7 +24,33 @@ import subprocess
 import sys
 import tempfile
 
-LLVM = "/opt/rocm/lib/llvm/bin"
+def _llvm_dir():
+    """llvm-objdump / llvm-readelf: $ROCM_PATH/lib/llvm/bin, what `hipcc --print-prog-name` names, /opt/rocm, then PATH"""
+    import shutil
+    cands = []
+    if os.environ.get("ROCM_PATH"):
+        cands.append(os.path.join(os.environ["ROCM_PATH"], "lib", "llvm", "bin"))
+    try:
+        out = subprocess.run(["hipcc", "--print-prog-name=llvm-objdump"], capture_output=True, text=True, timeout=30).stdout.strip()
+        if out and os.path.isabs(out):
+            cands.append(os.path.dirname(out))
+    except Exception:       # noqa: hipcc absent or too old for the flag
+        pass
+    cands.append("/opt/rocm/lib/llvm/bin")
+    for d in cands:
+        if os.path.exists(os.path.join(d, "llvm-objdump")) and os.path.exists(os.path.join(d, "llvm-readelf")):
+            return d
+    w = shutil.which("llvm-objdump")
+    if w and shutil.which("llvm-readelf"):
+        return os.path.dirname(w)
+    return None
+
+
+class ToolUnavailable(RuntimeError):
+    pass
+
+
+LLVM = _llvm_dir()
 MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
 MAX_LEAF_BYTES = 100 * 1024        # 2^15 dwords = 128 KiB is where relaxation starts; stay well below
 
@@ -75,6 +104,8 @@ def scan_callee(name, body, size):
 
 
 def check(path):
+    if LLVM is None:
+        raise ToolUnavailable("llvm-objdump / llvm-readelf not found ($ROCM_PATH, hipcc --print-prog-name, /opt/rocm, PATH)")
     findings, n_funcs, n_kernels, n_relaxed = [], 0, 0, 0
     for idx, (triple, blob) in enumerate(code_objects(path)):
         with tempfile.NamedTemporaryFile(suffix=".co", delete=False) as f:
@@ -107,8 +138,17 @@ def check(path):
 if __name__ == "__main__":
     here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     lib = sys.argv[1] if len(sys.argv) > 1 else os.path.join(here, "ginger-lib_amd", "libginger_hip.so")
-    found, nf, nk, nr = check(lib)
+    try:
+        found, nf, nk, nr = check(lib)
+    except (ToolUnavailable, subprocess.CalledProcessError, OSError) as e:
+        print("[long-branch check] could not run: %s" % e)
+        sys.exit(2)
     print("[long-branch check] %s: %d functions (%d kernels), %d s_getpc_b64, %d finding(s)" % (os.path.basename(lib), nf, nk, nr, len(found)))
     for f in found:
         print("  " + f)
-    sys.exit(1 if found else 0)
+    if found:
+        sys.exit(1)
+    if nf == 0 or nk == 0:
+        print("  no gfx950 code object / kernel found in the library: nothing was checked")
+        sys.exit(2)
+    sys.exit(0)

@@ -5,7 +5,7 @@ set -e
 SRC=$1; R=$2
 cp "$SRC/stats/run_kernel_stats.csv" "profiles/${R}_rocprofv3_kernel_stats_bench.csv"
 cp "$SRC/pmc_traffic.json" "profiles/${R}_pmc_traffic.json"
-for k in g1 g2 ntt; do for c in FETCH_SIZE WRITE_SIZE; do
+for k in g1 g2 g2m6 ntt; do for c in FETCH_SIZE WRITE_SIZE; do
   python3 tools/pmc_table.py "$SRC/${k}_$c/run_counter_collection.csv" msm_accumulate aff_round ntt_ > "profiles/${R}_pmc_${k}_$c.txt"
 done; done
 for k in g1 g2 g2m6; do
