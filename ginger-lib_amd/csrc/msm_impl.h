@@ -631,7 +631,9 @@ struct MsmJob {
         static const int env_fin = getenv("GH_AFF_FINISH_MAX") ? atoi(getenv("GH_AFF_FINISH_MAX")) : 64;
         // rounds: down to ~env_left points per bucket on average (the late rounds are short batches -- one inversion per
         // lane and round -- while the projective finish is dense work), and no bucket left with more than env_fin points
-        static const double env_left = getenv("GH_AFF_LEFTOVER") ? atof(getenv("GH_AFF_LEFTOVER")) : 4.5;
+        // (round 3, profiles/r03_g2_knobs.txt: on the towers the projective finish costs 11 tower products per point against the rounds' 6,
+        //  so fewer points are left to it: Fq3 1.5 (MNT6 G2 2^19: 5.75 -> 5.95 M/s together with the one-chunk scratch budget), Fq2 2.5)
+        static const double env_left = getenv("GH_AFF_LEFTOVER") ? atof(getenv("GH_AFF_LEFTOVER")) : (C::F::DEG == 3 ? 1.5 : (C::F::DEG == 2 ? 2.5 : 4.5));
         int R = 1;
         {
             const double mean = (double)n0 / (double)(total > 1 ? total - 1 : 1);
@@ -655,7 +657,9 @@ struct MsmJob {
         // Chunks of buckets: the scratch lists of the rounds are sized per chunk, so that a 2^24-pair key (or a G2 key with
         // its shift table) does not need 300 GB of them.  ~420 bytes x lanes per list entry: the staged inputs, the two
         // output lists, the running products and the descriptors of a chunk.
-        static const double env_scratch_gb = getenv("GH_AFF_SCRATCH_GB") ? atof(getenv("GH_AFF_SCRATCH_GB")) : 20.0;
+        // (default 64 GB since round 3: a 2^20-pair G2 MSM then runs as ONE chunk -- 14.0 -> 14.4 M/s on MNT4 G2; the budget is cut to what
+        //  is free next to the key anyway)
+        static const double env_scratch_gb = getenv("GH_AFF_SCRATCH_GB") ? atof(getenv("GH_AFF_SCRATCH_GB")) : 64.0;
         uint32_t K = 1;
         {
             size_t free_b = 0, total_b = 0;
