@@ -364,7 +364,7 @@ KeyHash content_hash(gh_curve_t curve, const uint64_t* bases, const uint8_t* inf
     std::vector<uint64_t> ch(2 * n_chunks + 4);
     unsigned nt = std::thread::hardware_concurrency();
     if (nt == 0) nt = 1;
-    if (nt > 16) nt = 16;
+    if (nt > 64) nt = 64;
     if (nt > n_chunks) nt = n_chunks ? (unsigned)n_chunks : 1;
     auto work = [&](unsigned t) {
         for (size_t c = t; c < n_chunks; c += nt) {
