@@ -43,8 +43,17 @@ int ensure_init() {
     {
         int least = 0, greatest = 0;   // numerically: least priority >= greatest priority
         HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        HIPCHK(hipStreamCreateWithPriority(&g.stream_acc, hipStreamDefault, least));
-        HIPCHK(hipStreamCreateWithPriority(&g.stream_red, hipStreamDefault, greatest));
+        // GH_PRIO_ACC / GH_PRIO_RED = low | normal | high: measurement knobs; defaults: accumulation lowest (the
+        // filler of the pipeline), reduction highest (short latency chains)
+        auto prio = [&](const char* env, int dflt) {
+            const char* v = getenv(env);
+            if (!v) return dflt;
+            if (!strcmp(v, "low")) return least;
+            if (!strcmp(v, "high")) return greatest;
+            return (least + greatest) / 2;
+        };
+        HIPCHK(hipStreamCreateWithPriority(&g.stream_acc, hipStreamDefault, prio("GH_PRIO_ACC", least)));
+        HIPCHK(hipStreamCreateWithPriority(&g.stream_red, hipStreamDefault, prio("GH_PRIO_RED", greatest)));
     }
     for (auto& ev : g.ev) HIPCHK(hipEventCreate(&ev));
     for (auto& sl : g.pev) for (auto& ev : sl) HIPCHK(hipEventCreate(&ev));
