@@ -139,17 +139,12 @@ __global__ void __launch_bounds__(NTT_MAX_TILE / 2, 2) ntt_pass_kernel(NttPassAr
                 for (int w = 0; w < NL; w++) lds[w * E + ea_w] = s.l[w];
             }
             __builtin_amdgcn_sched_barrier(0);
-            // where the difference only feeds the twiddle product (every stage but the last of a pass) it is taken lazily:
-            // a - b + p in (0, 2p) with no add-back pass -- the product accepts one operand below 2p (fp29.h) and reduces fully
+            d = fp_sub<P>(a, b);
+            __builtin_amdgcn_sched_barrier(0);
             if (h > 1) {
-                d = fp_sub_lazy<P>(a, b);
-                __builtin_amdgcn_sched_barrier(0);
                 uint32_t e = (uint32_t)(q & (h - 1)) << (A.log_n - (k - m));  // w_(2h)^i = w_N^(i N / 2h)
                 if (A.inverse) e = (N - e) & nmask;
                 d = fp_mul<P>(d, ld_fp(A.tw + e));
-            } else {
-                d = fp_sub<P>(a, b);
-                __builtin_amdgcn_sched_barrier(0);
             }
             if (to_lds) {
 #pragma unroll
