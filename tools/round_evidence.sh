@@ -14,4 +14,5 @@ python bench.py > "$OUT/bench_n1.json" 2> "$OUT/bench_n1.err" || { echo "bench f
 python bench.py --steps 5 --warmup 2 --no-2p24 --no-g2 --no-cpu-baseline > "$OUT/bench_n1_steps5.json" 2> "$OUT/bench_n1_steps5.err" || exit 1
 GH_DIST_BACKEND=gloo python bench.py --gpus 2 --steps 4 --warmup 1 --log-n 18 --no-ntt > "$OUT/bench_n2_gloo.json" 2> "$OUT/bench_n2_gloo.err" || { echo "n2 gloo failed"; tail -5 "$OUT/bench_n2_gloo.err"; }
 python bench.py --gpus 2 --steps 4 --warmup 1 --log-n 18 --no-ntt > "$OUT/bench_n2_rccl.json" 2> "$OUT/bench_n2_rccl.err" || { echo "n2 rccl failed"; tail -5 "$OUT/bench_n2_rccl.err"; }
+python3 tools/f_rows_bench.py 20 > "$OUT/f_rows.txt" 2> "$OUT/f_rows.err" || { echo "f_rows failed"; tail -3 "$OUT/f_rows.err"; }
 ls -la "$OUT"
