@@ -7,8 +7,13 @@
 // (entry 0 = infinity is never read), one thread per scalar walks its outerc digits with mixed additions
 // (add_assign_mixed, short_weierstrass_projective.rs:481-519, complete: doubling and infinity handled), and the result
 // is the same group element as the reference's (a projective representative; into_affine() is canonical).
-// Not the prover's hot path: the out-of-line curve functions of ec29.h are used throughout (small code, any curve).
+// The sums run on the MSM's own accumulation kernels (round 3): scalar i is "bucket" i and its list the table entries its
+// digits select (fixed_digits_kernel), so the per-row additions are the inlined XYZZ updates (G1) / lane-group updates (G2) of
+// msm_kernels.h instead of one out-of-line add_assign_mixed per row and thread -- 2^20 G1 scalars at window 14: 75 -> 31 ms.
+// GH_FIXED_NAIVE=1 (or a table with infinity entries: g of small order) keeps the one-thread-per-scalar kernel below.
+// Table building, normalisation and the chain generator use the out-of-line curve functions of ec29.h (small code, any curve).
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 #include "runtime.h"
@@ -21,7 +26,7 @@ namespace gh {
 template <class C>
 __global__ void __launch_bounds__(64)
 fixed_table_kernel(const Proj<C>* __restrict__ g_outer /* outerc points: 2^(window outer) g */, int window, uint32_t outerc,
-                   uint32_t last_in_window, Aff<C>* __restrict__ table) {
+                   uint32_t last_in_window, Aff<C>* __restrict__ table, uint32_t* __restrict__ mark_flag) {
     typedef typename C::FC F;
     const uint32_t in_window = 1u << window;
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -42,6 +47,7 @@ fixed_table_kernel(const Proj<C>* __restrict__ g_outer /* outerc points: 2^(wind
             out.y = F::mul(acc.y, zi);
         } else {
             F::comp(out.x, 0).l[0] = AFF_MARK;       // inner * g_outer = infinity (g of small order): marked, skipped below
+            *mark_flag = 1u;
         }
     }
     st_words(table + t, out);
@@ -78,6 +84,36 @@ fixed_msm_kernel(const Aff<C>* __restrict__ table, int window, uint32_t outerc, 
         acc = proj_madd_call<C>(acc, q);
     }
     st_words(out + i, acc);
+}
+
+// The same digits as bucket lists for the MSM's accumulation kernels (msm_impl.h: accumulate_lists): list i = the table entries
+// scalar i selects, at sorted[i * outerc ..], counts[i] of them; order = identity.  The digit rules are fixed_msm_kernel's.
+static __global__ void __launch_bounds__(256)
+fixed_digits_kernel(int window, uint32_t outerc, uint32_t scalar_size, const uint32_t* __restrict__ scalars, size_t n,
+                    uint32_t* __restrict__ sorted, uint32_t* __restrict__ starts, uint32_t* __restrict__ counts, uint32_t* __restrict__ order) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t s[25];
+#pragma unroll
+    for (int k = 0; k < 24; k++) s[k] = scalars[i * 24 + k];
+    s[24] = 0;
+    uint32_t* list = sorted + i * outerc;
+    uint32_t cnt = 0;
+    for (uint32_t outer = 0; outer < outerc; outer++) {
+        const uint32_t bit = outer * (uint32_t)window;
+        uint32_t nb = (uint32_t)window;
+        if (bit >= 753u) break;
+        if (bit + nb > 753u) nb = 753u - bit;
+        const uint32_t wi = bit >> 5, sh = bit & 31;
+        const uint64_t two = (uint64_t)s[wi] | ((uint64_t)s[wi + 1] << 32);
+        const uint32_t d = (uint32_t)(two >> sh) & ((1u << nb) - 1u);
+        if (d == 0) continue;
+        if (outer == outerc - 1 && d >= (1u << (scalar_size - (outerc - 1) * (uint32_t)window))) continue;
+        list[cnt++] = (outer << window) + d;
+    }
+    starts[i] = (uint32_t)(i * outerc);
+    counts[i] = cnt;
+    order[i] = (uint32_t)i;
 }
 
 // batch_normalization + into_affine of a vector of projective points (short_weierstrass_projective.rs:402-442, :663-678; the
@@ -189,6 +225,7 @@ struct FixedTable {
     int window = 0;
     uint32_t outerc = 0, scalar_size = 0;
     void* d_table = nullptr;
+    bool has_marks = false;     // some entry is the point at infinity (g = 0 or of small order): only fixed_msm_kernel skips those
 };
 
 template <class C> int build_table(const uint64_t* g_xyz, size_t scalar_size, int window, FixedTable* t) {
@@ -213,15 +250,21 @@ template <class C> int build_table(const uint64_t* g_xyz, size_t scalar_size, in
     }
     const size_t entries = (size_t)outerc << window;
     Proj<C>* d_g = nullptr;
+    uint32_t* d_flag = nullptr;
+    uint32_t h_flag = 0;
+    if (int rc = pool_get("fixed_flag", 4, (void**)&d_flag)) return rc;
     HIPCHK(hipMalloc(&t->d_table, entries * sizeof(Aff<C>)));
     hipError_t e = hipMalloc((void**)&d_g, outerc * sizeof(Proj<C>));
     if (e == hipSuccess) e = hipMemcpyAsync(d_g, gouter.data(), outerc * sizeof(Proj<C>), hipMemcpyHostToDevice, g.stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_flag, 0, 4, g.stream);
     if (e == hipSuccess) {
         hipLaunchKernelGGL((fixed_table_kernel<C>), dim3((unsigned)((entries + 63) / 64)), dim3(64), 0, g.stream, (const Proj<C>*)d_g,
-                           window, outerc, last_in_window, (Aff<C>*)t->d_table);
+                           window, outerc, last_in_window, (Aff<C>*)t->d_table, d_flag);
         e = hipGetLastError();
     }
+    if (e == hipSuccess) e = hipMemcpyAsync(&h_flag, d_flag, 4, hipMemcpyDeviceToHost, g.stream);
     if (e == hipSuccess) e = hipStreamSynchronize(g.stream);
+    t->has_marks = h_flag != 0;
     if (d_g) (void)hipFree(d_g);
     if (e != hipSuccess) {
         (void)hipFree(t->d_table);
@@ -233,6 +276,32 @@ template <class C> int build_table(const uint64_t* g_xyz, size_t scalar_size, in
     return GH_OK;
 }
 
+template <class C> const MsmOps* fixed_ops();
+template <> const MsmOps* fixed_ops<Mnt4G1>() { return msm_ops_mnt4753_g1(); }
+template <> const MsmOps* fixed_ops<Mnt4G2>() { return msm_ops_mnt4753_g2(); }
+template <> const MsmOps* fixed_ops<Mnt6G1>() { return msm_ops_mnt6753_g1(); }
+template <> const MsmOps* fixed_ops<Mnt6G2>() { return msm_ops_mnt6753_g2(); }
+
+// d_out[i] = sum over rows of table[outer][digit_outer(scalar i)] on g.stream (scalars already on the device)
+template <class C> int launch_fixed_sums(const FixedTable* t, const void* d_s, size_t n, void* d_o) {
+    static const bool naive = getenv("GH_FIXED_NAIVE") && atoi(getenv("GH_FIXED_NAIVE")) != 0;
+    if (naive || t->has_marks || n * (size_t)t->outerc >= ((size_t)1 << 31)) {
+        hipLaunchKernelGGL((fixed_msm_kernel<C>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, g.stream, (const Aff<C>*)t->d_table,
+                           t->window, t->outerc, t->scalar_size, (const uint32_t*)d_s, n, (Proj<C>*)d_o);
+        HIPCHK(hipGetLastError());
+        return GH_OK;
+    }
+    uint32_t *d_list = nullptr, *d_meta = nullptr;
+    int rc = pool_get("fixed_list", n * (size_t)t->outerc * 4, (void**)&d_list);
+    if (!rc) rc = pool_get("fixed_meta", n * 12, (void**)&d_meta);
+    if (rc) return rc;
+    uint32_t *d_starts = d_meta, *d_counts = d_meta + n, *d_order = d_meta + 2 * n;
+    hipLaunchKernelGGL(fixed_digits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, g.stream, t->window, t->outerc, t->scalar_size,
+                       (const uint32_t*)d_s, n, d_list, d_starts, d_counts, d_order);
+    HIPCHK(hipGetLastError());
+    return fixed_ops<C>()->acc_lists(t->d_table, d_list, d_starts, d_counts, d_order, (uint32_t)n, d_o, g.stream);
+}
+
 template <class C> int run_fixed(const FixedTable* t, const uint64_t* scalars, size_t n, uint64_t* out_xyz) {
     typedef typename C::F F;
     if (n == 0) return GH_OK;
@@ -241,9 +310,7 @@ template <class C> int run_fixed(const FixedTable* t, const uint64_t* scalars, s
     if (!rc) rc = pool_get("fixed_out", n * sizeof(Proj<C>), &d_o);
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(d_s, scalars, n * 96, hipMemcpyHostToDevice, g.stream));
-    hipLaunchKernelGGL((fixed_msm_kernel<C>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, g.stream, (const Aff<C>*)t->d_table,
-                       t->window, t->outerc, t->scalar_size, (const uint32_t*)d_s, n, (Proj<C>*)d_o);
-    HIPCHK(hipGetLastError());
+    if ((rc = launch_fixed_sums<C>(t, d_s, n, d_o))) return rc;
     std::vector<Proj<C>> host(n);
     HIPCHK(hipMemcpyAsync(host.data(), d_o, n * sizeof(Proj<C>), hipMemcpyDeviceToHost, g.stream));
     HIPCHK(hipStreamSynchronize(g.stream));
@@ -271,8 +338,7 @@ template <class C> int run_fixed_affine(const FixedTable* t, const uint64_t* sca
     if (!rc) rc = pool_get("fixed_zp", n * sizeof(FT), &d_zp);
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(d_s, scalars, n * 96, hipMemcpyHostToDevice, g.stream));
-    hipLaunchKernelGGL((fixed_msm_kernel<C>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, g.stream, (const Aff<C>*)t->d_table,
-                       t->window, t->outerc, t->scalar_size, (const uint32_t*)d_s, n, (Proj<C>*)d_o);
+    if ((rc = launch_fixed_sums<C>(t, d_s, n, d_o))) return rc;
     const size_t threads = (n + NORM_RUN - 1) / NORM_RUN;
     hipLaunchKernelGGL((fixed_normalize_kernel<C>), dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, g.stream, (const Proj<C>*)d_o, n, canonical,
                        (uint32_t*)d_xy, (uint8_t*)d_inf, (FT*)d_zp);

@@ -93,6 +93,20 @@ template <class C> int make_salts(Aff<C>* out) {
     return GH_OK;
 }
 
+// salt points S0 = G, S1 = 2G (internal affine form) for the accumulate kernels' detour, resident once per curve
+template <class C> int device_salts(Aff<C>** out) {
+    static Aff<C>* d_salts = nullptr;
+    if (!d_salts) {
+        Aff<C> hs[2];
+        if (int src = make_salts<C>(hs)) return src;
+        HIPCHK(hipMalloc((void**)&d_salts, sizeof(hs)));
+        HIPCHK(hipMemcpy(d_salts, hs, sizeof(hs), hipMemcpyHostToDevice));
+        g.at_shutdown.push_back([] { if (d_salts) hipFree(d_salts); d_salts = nullptr; });
+    }
+    *out = d_salts;
+    return GH_OK;
+}
+
 template <class C>
 int upload_bases(const uint64_t* bases, const uint8_t* infinity, size_t n, int canonical, BasesBase** out) {
     typedef typename C::F F;
@@ -393,8 +407,13 @@ struct MsmJob {
         if (C::F::DEG == 2 && !split_reduce_off) tpw = 32;     // lane pairs  (msm_kernels.h 5b)
         if (C::F::DEG == 3 && !split_reduce_off) tpw = 16;     // lane triples, 48 lanes busy
         sw = tpw == 64 ? 6 : (tpw == 32 ? 5 : 4);
+        auto programs = [&](int l1) { return (size_t)RW * ((Q + (uint32_t)tpw * l1 - 1) / ((uint32_t)tpw * l1)); };
         L1 = MSM_REDUCE_L;
-        while (L1 > 4 && (size_t)RW * ((Q + (uint32_t)(tpw / 2) * L1 - 1) / ((uint32_t)(tpw / 2) * L1)) <= 1024) L1 >>= 1;
+        while (L1 > 4 && programs(L1 / 2) <= 1024) L1 >>= 1;
+        // more programs than SIMDs even at L1 = 16 (the per-window path: 48 windows x 32 segments at 2^20 pairs; every path at
+        // 2^24): twice the segment length halves the programs -- 768 instead of 1536 at 2^20, so that no SIMD carries two -- and
+        // the tree / scan steps per bucket (round 3: reduce 6.7 -> 5.9 ms at 2^20 per-window, 32.3 -> 29.8 ms at 2^24)
+        if (L1 == MSM_REDUCE_L && programs(L1) > 1024) L1 = 2 * MSM_REDUCE_L;
         if (env_L1 == 4 || env_L1 == 8 || env_L1 == 16 || env_L1 == 32) L1 = env_L1;
         const uint32_t seg_slots = (uint32_t)tpw * (uint32_t)L1;
         segs_per_window = (Q + seg_slots - 1) / seg_slots;
@@ -414,16 +433,7 @@ struct MsmJob {
             const int mode = env_aff >= 0 ? env_aff : g.affine_mode;
             tree = mode == 1 || (mode == 2 && C::F::DEG >= 2 && (size_t)W * n >= ((size_t)1 << 21));
         }
-        // salt points S0 = G, S1 = 2G (internal affine form) for the accumulate kernel's detour
-        static Aff<C>* d_salts = nullptr;
-        if (!d_salts) {
-            Aff<C> hs[2];
-            if (int src = make_salts<C>(hs)) return src;
-            HIPCHK(hipMalloc((void**)&d_salts, sizeof(hs)));
-            HIPCHK(hipMemcpy(d_salts, hs, sizeof(hs), hipMemcpyHostToDevice));
-            g.at_shutdown.push_back([] { if (d_salts) hipFree(d_salts); d_salts = nullptr; });
-        }
-        salts = d_salts;
+        if (int src = device_salts<C>(&salts)) return src;
         // Heavy threshold.  Buckets are walked longest first, one per thread at ~78 us per addition
         // (2 waves / SIMD), so a bucket of s entries is free as long as s * 78 us stays well inside the
         // kernel's own duration (~ W n / 1.65e9 s); beyond that it would be the tail, and is split.
@@ -870,6 +880,32 @@ struct MsmJob {
     }
 };
 
+// The accumulation kernels over caller-made lists (fixed_base.hip: one "bucket" per scalar, its list the table entries its
+// digits select): out[g] = sum of points[sorted[starts[g] + k] & 0x7FFFFFFF] (bit 31: negated), k < counts[g], for the
+// `total` lists in the order `order` names them; no heavy-bucket chunks.  Same kernels, same complete addition (doubling through
+// the salt detour, P + (-P), infinity) as the MSM's projective path.
+template <class C>
+int accumulate_lists(const void* points, const uint32_t* sorted, const uint32_t* starts, const uint32_t* counts,
+                     const uint32_t* order, uint32_t total, void* out_proj, hipStream_t st) {
+    if (total == 0) return GH_OK;
+    Aff<C>* salts = nullptr;
+    if (int rc = device_salts<C>(&salts)) return rc;
+    if constexpr (C::F::DEG == 1) {
+        hipLaunchKernelGGL((msm_accumulate_xyzz_kernel<C>), dim3((unsigned)(((size_t)total + 255) / 256)), dim3(256), 0, st,
+                           (const Aff<C>*)points, sorted, starts, counts, order, total, (const Aff<C>*)salts, (Proj<C>*)out_proj,
+                           (const uint32_t*)nullptr, 0u, 0u, 0u, (Proj<C>*)nullptr, 0u, 0u);
+    } else {
+        typedef typename std::conditional<std::is_same<C, Mnt4G2>::value, F2S<P4, 13, GH_F2S_DUAL != 0>, F3S<P6, 11, GH_F3S_TRIPLE>>::type FS;
+        constexpr int LANES = FS::LANES;
+        const size_t waves = ((size_t)total + (64 / LANES) - 1) / (64 / LANES);
+        hipLaunchKernelGGL((msm_accumulate_split_kernel<C, FS, LANES>), dim3((unsigned)((waves * 64 + 255) / 256)), dim3(256), 0, st,
+                           (const Aff<C>*)points, sorted, starts, counts, order, total, (const Aff<C>*)salts, (Proj<C>*)out_proj,
+                           (const uint32_t*)nullptr, 0u, 0u, 0u, (Proj<C>*)nullptr);
+    }
+    HIPCHK(hipGetLastError());
+    return GH_OK;
+}
+
 // `count` MSMs back to back.  With count > 1 the stages are pipelined over three streams and two
 // buffer slots: while MSM k accumulates (stream_acc), the bucket sort of MSM k+1 (g.stream) and the
 // bucket reduction + host fold of MSM k-1 (stream_red, host) run beside it -- the sort is
@@ -992,7 +1028,7 @@ template <class C> int to_affine_host(const uint64_t* xyz, uint64_t* out_xy, uin
         static const MsmOps ops = {&upload_bases<CURVE>, &msm_run<CURVE>, &msm_host<CURVE>,    \
                                    &proj_add_host<CURVE>, &to_affine_host<CURVE>,              \
                                    &precompute_bases<CURVE>, &msm_batch<CURVE>,                \
-                                   &proj_mul_host<CURVE>, &proj_neg_host<CURVE>};                                     \
+                                   &proj_mul_host<CURVE>, &proj_neg_host<CURVE>, &accumulate_lists<CURVE>};           \
         return &ops;                                                                           \
     }                                                                                          \
     }

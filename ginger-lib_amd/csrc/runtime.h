@@ -91,6 +91,8 @@ struct MsmOps {
     int (*batch)(BasesBase* const* hs, const void* const* d_scalars, const size_t* n_scalars, int count, uint64_t* out_xyz);
     int (*proj_mul)(const uint64_t* p_xyz, const uint64_t* scalar12, uint64_t* out_xyz);
     int (*proj_neg)(uint64_t* xyz);
+    int (*acc_lists)(const void* points, const uint32_t* sorted, const uint32_t* starts, const uint32_t* counts,
+                     const uint32_t* order, uint32_t total, void* out_proj, hipStream_t st);
 };
 const MsmOps* msm_ops_mnt4753_g1();
 const MsmOps* msm_ops_mnt4753_g2();

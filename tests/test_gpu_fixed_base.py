@@ -95,6 +95,43 @@ def test_fixed_base_short_scalar_size_and_affine_output(gpu, curve):
         assert inf_m[0] == 1 and inf_m[1] == 0
 
 
+def test_fixed_base_list_kernels_equal_the_per_scalar_kernel(gpu):
+    """The sums run on the MSM's accumulation kernels (fixed_base.hip: one list per scalar); GH_FIXED_NAIVE=1 keeps the
+    one-thread-per-scalar kernel of round 2.  Both must give the same affine rows -- the naive one in a child process, because
+    the switch is read once per process."""
+    import hashlib, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = {}
+    for curve in ("mnt4753_g1", "mnt4753_g2", "mnt6753_g2"):
+        C = pyref.CURVES[curve]
+        n = 500
+        s = S.random_scalars_np(n, seed=123, below=C.order)
+        s[0] = 0
+        s[1, 1:] = 0                                              # a scalar with one non-zero row
+        tab = gpu.FixedBaseMSM(curve, S.proj_array(C, C.G), 753, 9)
+        xy, inf = tab.multi_scalar_mul_affine(s, canonical=True)
+        tab.free()
+        digests[curve] = hashlib.sha256(xy.tobytes() + inf.tobytes()).hexdigest()
+        assert inf[0] == 1 and not inf[1:].any()
+    child = (
+        "import sys, hashlib, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import pyref, support as S\n"
+        "from __graft_entry__ import _load_pkg\n"
+        "gl = _load_pkg(); gl.init()\n"
+        "for curve in ('mnt4753_g1', 'mnt4753_g2', 'mnt6753_g2'):\n"
+        "    C = pyref.CURVES[curve]\n"
+        "    s = S.random_scalars_np(500, seed=123, below=C.order); s[0] = 0; s[1, 1:] = 0\n"
+        "    tab = gl.FixedBaseMSM(curve, S.proj_array(C, C.G), 753, 9)\n"
+        "    xy, inf = tab.multi_scalar_mul_affine(s, canonical=True); tab.free()\n"
+        "    print(curve, hashlib.sha256(xy.tobytes() + inf.tobytes()).hexdigest())\n"
+    ) % (root, os.path.join(root, "tests"))
+    env = dict(os.environ, GH_FIXED_NAIVE="1")
+    out = subprocess.run([sys.executable, "-c", child], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    got = dict(l.split() for l in out.stdout.strip().splitlines() if l.startswith("mnt"))
+    assert got == digests
+
+
 def test_fixed_base_generator_scale(gpu):
     """generator-sized call (generator.rs:243: one multi_scalar_mul per query): 2^16 scalars on G1, spot-checked"""
     curve = "mnt4753_g1"
