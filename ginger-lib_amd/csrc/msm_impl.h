@@ -488,7 +488,11 @@ struct MsmJob {
         static const char* env_sort = getenv("GH_SORT");
         const uint32_t tile = entries > ((size_t)1 << 27) ? 65536u : 16384u;
         uint32_t bin_shift = 8;
-        while (((total + ((size_t)1 << bin_shift) - 1) >> bin_shift) > (size_t)MSM_PART_MAX_BINS) bin_shift++;
+        auto bins_at = [&](uint32_t sh) { return (total + ((size_t)1 << sh) - 1) >> sh; };
+        while (bins_at(bin_shift) > 1024) bin_shift++;
+        // more than 2^23 buckets (2^24 pairs per window at c = 19: 40 x 2^18): up to MSM_PART_MAX_BINS bins of 2^13 buckets rather
+        // than the device-scope atomics (sort 65 ms there)
+        if (bin_shift > 13 && bins_at(13) <= (size_t)MSM_PART_MAX_BINS) bin_shift = 13;
         bool part_sort = entries >= ((size_t)1 << 22) && n >= tile && bin_shift <= 13;
         if (env_sort && !strcmp(env_sort, "atomic")) part_sort = false;
         if (env_sort && !strcmp(env_sort, "part") && n >= tile && bin_shift <= 13) part_sort = true;

@@ -324,14 +324,14 @@ msm_digits_kernel(const uint32_t* __restrict__ scalars, const uint8_t* __restric
 // The histogram + scatter pair above issues two device-scope atomics per list entry on a counter array that is
 // far larger than LDS (2 x 37.7 M at 2^20 pairs: 3.4 ms, 12 ms at 2^22).  For large inputs the lists are built by a
 // two-level counting sort whose atomics all stay in LDS:
-//   A  the bucket range is cut into NB <= 1024 bins of 2^bin_shift buckets; every block takes a tile of consecutive
+//   A  the bucket range is cut into NB <= 1024 (2048 beyond 2^23 buckets) bins of 2^bin_shift buckets; every block takes a tile of consecutive
 //      entries e = w n + i, counts them per bin in LDS (msm_part_hist_kernel -> block_hist[bin][block]), an exclusive
 //      scan over that array gives every (bin, block) its slice of the partitioned array, and the same tile is read
 //      again to write (bucket, list value) pairs there (msm_part_scatter_kernel);
 //   B  one block per bin: per-bucket counts in LDS, block scan -> counts[] / starts[], second sweep -> sorted[].
 // Result: the same counts / starts / sorted arrays as the atomic path (order inside a bucket is arbitrary in both).
 constexpr int MSM_PART_THREADS = 256;
-constexpr int MSM_PART_MAX_BINS = 1024;
+constexpr int MSM_PART_MAX_BINS = 2048;   // (1024 unless the buckets need more: msm_impl.h, launch_sort)
 struct MsmPartArgs {
     const int32_t* digits;
     size_t entries;        // W * n
@@ -388,6 +388,7 @@ static __global__ void __launch_bounds__(MSM_PART_THREADS) msm_part_scatter_kern
 // one block per bin; dynamic LDS: 2^bin_shift counters.  block_off[bin * n_blocks] is where the bin's pairs start
 // (block_off has n_bins * n_blocks + 1 elements: the last one is the total).
 constexpr int MSM_BIN_THREADS = 1024;
+constexpr int MSM_BIN_UNROLL = 8;
 static __global__ void __launch_bounds__(MSM_BIN_THREADS) msm_bin_sort_kernel(const uint2* __restrict__ part, const uint32_t* __restrict__ block_off,
                                                                              uint32_t n_blocks, uint32_t bin_shift, uint32_t total,
                                                                              uint32_t* __restrict__ counts, uint32_t* __restrict__ starts,
@@ -398,7 +399,18 @@ static __global__ void __launch_bounds__(MSM_BIN_THREADS) msm_bin_sort_kernel(co
     const uint32_t lo = block_off[(size_t)bin * n_blocks], hi = block_off[(size_t)(bin + 1) * n_blocks];
     for (uint32_t i = threadIdx.x; i < size; i += MSM_BIN_THREADS) cnt[i] = 0;
     __syncthreads();
-    for (uint32_t k = lo + threadIdx.x; k < hi; k += MSM_BIN_THREADS) atomicAdd(&cnt[part[k].x - b0], 1u);
+    // both sweeps read MSM_BIN_UNROLL pairs per thread before the first LDS atomic: a bin of 2^19 pairs (2^24 pairs per window) is
+    // 512 dependent load -> atomic -> store rounds per thread otherwise (44 ms for the 1280 bins there; round 3)
+    for (uint32_t k = lo + threadIdx.x; k < hi; k += MSM_BIN_THREADS * MSM_BIN_UNROLL) {
+        uint32_t bx[MSM_BIN_UNROLL];
+#pragma unroll
+        for (int u = 0; u < MSM_BIN_UNROLL; u++) {
+            const uint32_t kk = k + (uint32_t)u * MSM_BIN_THREADS;
+            bx[u] = kk < hi ? part[kk].x : 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (int u = 0; u < MSM_BIN_UNROLL; u++) if (bx[u] != 0xFFFFFFFFu) atomicAdd(&cnt[bx[u] - b0], 1u);
+    }
     __syncthreads();
     // exclusive scan of cnt: each thread owns `per` consecutive counters
     const uint32_t per = size / MSM_BIN_THREADS > 0 ? size / MSM_BIN_THREADS : 1;
@@ -422,9 +434,15 @@ static __global__ void __launch_bounds__(MSM_BIN_THREADS) msm_bin_sort_kernel(co
         }
     }
     __syncthreads();
-    for (uint32_t k = lo + threadIdx.x; k < hi; k += MSM_BIN_THREADS) {
-        const uint2 pv = part[k];
-        sorted[atomicAdd(&cnt[pv.x - b0], 1u)] = pv.y;
+    for (uint32_t k = lo + threadIdx.x; k < hi; k += MSM_BIN_THREADS * MSM_BIN_UNROLL) {
+        uint2 pv[MSM_BIN_UNROLL];
+#pragma unroll
+        for (int u = 0; u < MSM_BIN_UNROLL; u++) {
+            const uint32_t kk = k + (uint32_t)u * MSM_BIN_THREADS;
+            pv[u] = kk < hi ? part[kk] : make_uint2(0xFFFFFFFFu, 0u);
+        }
+#pragma unroll
+        for (int u = 0; u < MSM_BIN_UNROLL; u++) if (pv[u].x != 0xFFFFFFFFu) sorted[atomicAdd(&cnt[pv[u].x - b0], 1u)] = pv[u].y;
     }
 }
 
