@@ -486,6 +486,7 @@ struct MsmJob {
         // scatter with device-scope atomics (fewer launches).  GH_SORT=atomic / part forces one of them where it applies.
         const size_t entries = (size_t)W * n;
         static const char* env_sort = getenv("GH_SORT");
+        static const bool sort_ordered = !(getenv("GH_SORT_ORDERED") && atoi(getenv("GH_SORT_ORDERED")) == 0);
         const uint32_t tile = entries > ((size_t)1 << 27) ? 65536u : 16384u;
         uint32_t bin_shift = 8;
         auto bins_at = [&](uint32_t sh) { return (total + ((size_t)1 << sh) - 1) >> sh; };
@@ -523,7 +524,7 @@ struct MsmJob {
             if ((rc = device_scan(block_hist, block_off, cells, nm, st))) return rc;
             hipLaunchKernelGGL(msm_part_scatter_kernel, dim3(a.n_blocks), dim3(MSM_PART_THREADS), 0, st, a, (const uint32_t*)block_off, part);
             hipLaunchKernelGGL(msm_bin_sort_kernel, dim3(a.n_bins), dim3(MSM_BIN_THREADS), (size_t)4 << bin_shift, st, (const uint2*)part,
-                               (const uint32_t*)block_off, a.n_blocks, bin_shift, (uint32_t)total, counts, starts, sorted);
+                               (const uint32_t*)block_off, a.n_blocks, bin_shift, (uint32_t)total, counts, starts, sorted, sort_ordered ? 1u : 0u);
             HIPCHK(hipGetLastError());
         } else {
             HIPCHK(hipMemsetAsync(counts, 0, total * 4, st));

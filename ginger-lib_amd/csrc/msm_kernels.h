@@ -392,7 +392,7 @@ constexpr int MSM_BIN_UNROLL = 8;
 static __global__ void __launch_bounds__(MSM_BIN_THREADS) msm_bin_sort_kernel(const uint2* __restrict__ part, const uint32_t* __restrict__ block_off,
                                                                              uint32_t n_blocks, uint32_t bin_shift, uint32_t total,
                                                                              uint32_t* __restrict__ counts, uint32_t* __restrict__ starts,
-                                                                             uint32_t* __restrict__ sorted) {
+                                                                             uint32_t* __restrict__ sorted, uint32_t ordered) {
     extern __shared__ uint32_t cnt[];                 // 2^bin_shift
     __shared__ uint32_t wsum[MSM_BIN_THREADS / 64];
     const uint32_t bin = blockIdx.x, size = 1u << bin_shift, b0 = bin << bin_shift;
@@ -434,15 +434,24 @@ static __global__ void __launch_bounds__(MSM_BIN_THREADS) msm_bin_sort_kernel(co
         }
     }
     __syncthreads();
-    for (uint32_t k = lo + threadIdx.x; k < hi; k += MSM_BIN_THREADS * MSM_BIN_UNROLL) {
+    // Second sweep, in the order of the partitioned array: a bin's pairs arrive tile by tile, i.e. by ascending entry number
+    // e = w n + i, and 1024 consecutive pairs of a bin are about one window's worth -- so with a barrier after every 1024 pairs
+    // each bucket's list comes out ordered by window (merged buckets) / by base index (per-window buckets).  The accumulation
+    // walks its lists in step, so ordered lists keep the gathers of the waves in flight closer together: 1-2 % on the
+    // accumulation and on the pipelined batch at 2^20 .. 2^24, and the sweep itself is no slower with the barriers
+    // (profiles/r03_sort_order_ab.txt, GH_SORT_ORDERED=0 = without them).  The loads of eight steps are issued together.
+    for (uint32_t base = lo; base < hi; base += MSM_BIN_THREADS * MSM_BIN_UNROLL) {      // uniform trip count: barriers inside
         uint2 pv[MSM_BIN_UNROLL];
 #pragma unroll
         for (int u = 0; u < MSM_BIN_UNROLL; u++) {
-            const uint32_t kk = k + (uint32_t)u * MSM_BIN_THREADS;
+            const uint32_t kk = base + (uint32_t)u * MSM_BIN_THREADS + threadIdx.x;
             pv[u] = kk < hi ? part[kk] : make_uint2(0xFFFFFFFFu, 0u);
         }
 #pragma unroll
-        for (int u = 0; u < MSM_BIN_UNROLL; u++) if (pv[u].x != 0xFFFFFFFFu) sorted[atomicAdd(&cnt[pv[u].x - b0], 1u)] = pv[u].y;
+        for (int u = 0; u < MSM_BIN_UNROLL; u++) {
+            if (pv[u].x != 0xFFFFFFFFu) sorted[atomicAdd(&cnt[pv[u].x - b0], 1u)] = pv[u].y;
+            if (ordered) __syncthreads();       // (GH_SORT_ORDERED=0: the A/B switch)
+        }
     }
 }
 
