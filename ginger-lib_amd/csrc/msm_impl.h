@@ -414,7 +414,7 @@ struct MsmJob {
         // 2^24): twice the segment length halves the programs -- 768 instead of 1536 at 2^20, so that no SIMD carries two -- and
         // the tree / scan steps per bucket (round 3: reduce 6.7 -> 5.9 ms at 2^20 per-window, 32.3 -> 29.8 ms at 2^24)
         if (L1 == MSM_REDUCE_L && programs(L1) > 1024) L1 = 2 * MSM_REDUCE_L;
-        if (env_L1 == 4 || env_L1 == 8 || env_L1 == 16 || env_L1 == 32) L1 = env_L1;
+        if (env_L1 >= 4 && env_L1 <= 128 && (env_L1 & (env_L1 - 1)) == 0) L1 = env_L1;
         const uint32_t seg_slots = (uint32_t)tpw * (uint32_t)L1;
         segs_per_window = (Q + seg_slots - 1) / seg_slots;
         L2 = (int)((segs_per_window + tpw - 1) / tpw);         // items per lane group, level 2 (one wave per window)
