@@ -441,6 +441,7 @@ def main():
                 t_out = rb24.msm_dev(d24, n24)
             tb_ms = (time.perf_counter() - t1) * 1e3 / K24
             ttm = gl.msm_last_timing()
+            gl.msm_batch_dev([(rb24, d24, n24)] * 2)        # untimed: the second pipeline slot's buffers are allocated on first use
             t1 = time.perf_counter()
             b_out = gl.msm_batch_dev([(rb24, d24, n24)] * K24)
             bt_ms = (time.perf_counter() - t1) * 1e3 / K24

@@ -344,6 +344,11 @@ struct MsmJob {
              *size_cursor = nullptr, *chunk_start = nullptr, *plan = nullptr;
     Proj<C>*buckets = nullptr, *seg_out = nullptr, *win_out = nullptr, *partials = nullptr;
     bool solo = false;               // a batch of one (set by msm_batch): nothing runs beside this MSM
+    bool last = false;               // the last MSM of its batch: its reduction has nothing to hide behind
+    int es = 0;                      // event set (g.pev[es]): the job's index in its batch mod 4, so that the sort of job k+1 can be
+                                     // issued while job k-1 (same buffer slot) still waits for its window sums
+    bool lean = false;               // bucket reduction in its lane-level form (launch_reduce)
+    Proj<C>* lane_out = nullptr;
     // affine rounds (aff_kernels.h)
     bool tree = false;
     int tree_rounds = 0;
@@ -354,9 +359,11 @@ struct MsmJob {
     std::chrono::steady_clock::time_point t_begin;
     gh_msm_timing_t tm{};
 
+    // staging buffers per job in flight (set = the job's event set, k & 3): job k+1 is prepared while job k-1 -- same buffer slot --
+    // still has its window sums on the way, so the two must not share (or re-allocate) a pinned buffer
     static int pinned(int slot, int which, size_t bytes, void** out) {
-        static void* p[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
-        static size_t cap[2][2] = {{0, 0}, {0, 0}};
+        static void* p[4][2] = {};
+        static size_t cap[4][2] = {};
         static bool registered = false;
         if (!registered) {   // gh_shutdown releases the staging buffers
             registered = true;
@@ -415,6 +422,14 @@ struct MsmJob {
         // the tree / scan steps per bucket (round 3: reduce 6.7 -> 5.9 ms at 2^20 per-window, 32.3 -> 29.8 ms at 2^24)
         if (L1 == MSM_REDUCE_L && programs(L1) > 1024) L1 = 2 * MSM_REDUCE_L;
         if (env_L1 >= 4 && env_L1 <= 128 && (env_L1 & (env_L1 - 1)) == 0) L1 = env_L1;
+        // Lean reduction (G1, inside a batch): level 1 stops after its serial part and hands every LANE's two sums to level 2
+        // (msm_kernels.h, mode 2) -- 2 L1 - 1 steps per segment instead of 2 L1 + 17, a third fewer wave instructions for
+        // the reduction, which inside a batch cost the accumulation beside it 3.2 of its 23.4 ms per MSM at 2^20 (measured by
+        // leaving the reduction out).  The chain is longer (level 2 then folds 64 x as many items per window: 6.5 + 8.3 ms inside
+        // a batch at 2^20 against 8.8 + 3.0), so an MSM that runs alone and the last one of a batch keep the segment form, and
+        // so do short accumulations the longer chain would not fit behind (2^18 pairs: 12.8 instead of 8.0 ms per MSM).
+        static const int env_lean = getenv("GH_REDUCE_LEAN") ? atoi(getenv("GH_REDUCE_LEAN")) : -1;
+        lean = C::F::DEG == 1 && tpw == 64 && (env_lean >= 0 ? env_lean != 0 : (!solo && !last && (size_t)W * n >= ((size_t)1 << 25)));
         const uint32_t seg_slots = (uint32_t)tpw * (uint32_t)L1;
         segs_per_window = (Q + seg_slots - 1) / seg_slots;
         L2 = (int)((segs_per_window + tpw - 1) / tpw);         // items per lane group, level 2 (one wave per window)
@@ -466,9 +481,14 @@ struct MsmJob {
         POOL("buckets", buckets, slots * sizeof(Proj<C>))
         POOL("seg_out", seg_out, (size_t)RW * segs_per_window * 3 * sizeof(Proj<C>))
         POOL("win_out", win_out, (size_t)3 * RW * 3 * sizeof(Proj<C>))
+        // (also for the last MSM of a batch, which does not use it: a buffer that is first allocated in the middle of a later batch
+        //  costs that batch a device-wide wait -- 9 ms at 2^20)
+        if (lean || (C::F::DEG == 1 && tpw == 64 && !solo && (size_t)W * n >= ((size_t)1 << 25))) {
+            POOL("lane_out", lane_out, (size_t)RW * segs_per_window * 64 * 2 * sizeof(Proj<C>))
+        }
 #undef POOL
-        if ((rc = pinned(slot, 0, 512, (void**)&hplan))) return rc;
-        if ((rc = pinned(slot, 1, (size_t)9 * RW * sizeof(Proj<C>), (void**)&hw))) return rc;
+        if ((rc = pinned(es, 0, 512, (void**)&hplan))) return rc;
+        if ((rc = pinned(es, 1, (size_t)9 * RW * sizeof(Proj<C>), (void**)&hw))) return rc;
         return GH_OK;
     }
 
@@ -479,7 +499,7 @@ struct MsmJob {
         // keys a wave combines into one atomic each before falling back to per-lane atomics (wave_agg_inc)
         static const int env_agg = getenv("GH_AGG_ITERS") ? atoi(getenv("GH_AGG_ITERS")) : -1;
         const int agg_iters = env_agg >= 0 ? env_agg : 12;
-        HIPCHK(hipEventRecord(g.pev[slot][0], st));
+        HIPCHK(hipEventRecord(g.pev[es][0], st));
         HIPCHK(hipMemsetAsync(size_hist, 0, MSM_SIZE_BINS * 4, st));
         HIPCHK(hipMemsetAsync(plan, 0, 64, st));
         // Bucket lists.  Large inputs: two-level counting sort with LDS atomics only (msm_kernels.h 2a); small ones: histogram +
@@ -545,7 +565,7 @@ struct MsmJob {
                                (const int32_t*)digits, n, W, win_stride, merged ? (uint32_t)h->n : 0u, cursor, sorted, agg_iters, merged ? 1u : 0u);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(hplan, plan, 32, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipEventRecord(g.pev[slot][1], st));
+        HIPCHK(hipEventRecord(g.pev[es][1], st));
         return GH_OK;
     }
 
@@ -553,7 +573,7 @@ struct MsmJob {
     int launch_accumulate(hipStream_t st) {
         if (n == 0) return GH_OK;
         int rc;
-        HIPCHK(hipEventSynchronize(g.pev[slot][1]));
+        HIPCHK(hipEventSynchronize(g.pev[es][1]));
         n_heavy = hplan[0]; n_chunks = hplan[1];
         tm.accumulate_madds = hplan[2];
         if (n_heavy > max_heavy || n_chunks > max_chunks) { g_err = "internal: heavy-bucket plan out of range"; return GH_E_HIP; }
@@ -567,7 +587,7 @@ struct MsmJob {
         const void* src_points = merged ? h->d_table : h->d_points;
         if (slots > total)   // padding slots of the last pseudo-window: infinity (Z = 0)
             HIPCHK(hipMemsetAsync((void*)(buckets + total), 0, (slots - total) * sizeof(Proj<C>), st));
-        HIPCHK(hipEventRecord(g.pev[slot][2], st));
+        HIPCHK(hipEventRecord(g.pev[es][2], st));
         if (tree) {   // may clear `tree` when its scratch does not fit next to the key: the projective kernel takes over
             if ((rc = launch_tree(st))) return rc;
         }
@@ -617,13 +637,13 @@ struct MsmJob {
         }
         }
         HIPCHK(hipGetLastError());
-        HIPCHK(hipEventRecord(g.pev[slot][3], st));
+        HIPCHK(hipEventRecord(g.pev[es][3], st));
         if (n_heavy > 0) {   // one wave per heavy bucket adds its chunk sums
             hipLaunchKernelGGL((msm_heavy_combine_kernel<C>), dim3(n_heavy), dim3(64), lds_wave, st, (const Proj<C>*)partials,
                                (const uint32_t*)order, (const uint32_t*)chunk_start, buckets);
             HIPCHK(hipGetLastError());
         }
-        HIPCHK(hipEventRecord(g.pev[slot][4], st));
+        HIPCHK(hipEventRecord(g.pev[es][4], st));
         return GH_OK;
     }
 
@@ -825,7 +845,25 @@ struct MsmJob {
             // per lane instead of 680) -- inside a batch the reduction must fit beside the accumulation's waves (256 registers).
             static const int env_w = getenv("GH_REDUCE_WAVES") ? atoi(getenv("GH_REDUCE_WAVES")) : 0;
             const bool one_wave = env_w ? env_w == 1 : solo;
-            if (one_wave) {
+            if (lean) {
+                // level 1: serial part only, (run, wacc) per lane; level 2 per window: the weighted program over the lanes' run (item =
+                // segment * 64 + lane, so its A = sum segment * run and Bv = sum lane * run) and the plain sum of their wacc
+                const uint32_t lanes_per_window = (uint32_t)segs_per_window * 64u;
+                WaveReduceIn<C> i0l{buckets, 1, 0, Q, 2, (uint32_t)total};
+                WaveReduceIn<C> l0{lane_out, 2, 0, lanes_per_window, 0, all}, l1{lane_out, 2, 1, lanes_per_window, 1, all};
+                const unsigned nb2l = (unsigned)(2 * RW);
+                if (one_wave) {
+                    hipLaunchKernelGGL((msm_wave_reduce_kernel<C, 1>), dim3((nb1 + wpb - 1) / wpb), dim3(64 * wpb), lds_wave * wpb, st,
+                                       i0l, none, none, nb1, 1u, segs_per_window, L1, (const Aff<C>*)salts, lane_out, slabs);
+                    hipLaunchKernelGGL((msm_wave_reduce_kernel<C, 1>), dim3((nb2l + wpb - 1) / wpb), dim3(64 * wpb), lds_wave * wpb, st,
+                                       l0, l1, none, (uint32_t)RW, 2u, 1u, (int)segs_per_window, (const Aff<C>*)salts, win_out, slabs);
+                } else {
+                    hipLaunchKernelGGL((msm_wave_reduce_kernel<C, 2>), dim3((nb1 + wpb - 1) / wpb), dim3(64 * wpb), lds_wave * wpb, st,
+                                       i0l, none, none, nb1, 1u, segs_per_window, L1, (const Aff<C>*)salts, lane_out, slabs);
+                    hipLaunchKernelGGL((msm_wave_reduce_kernel<C, 2>), dim3((nb2l + wpb - 1) / wpb), dim3(64 * wpb), lds_wave * wpb, st,
+                                       l0, l1, none, (uint32_t)RW, 2u, 1u, (int)segs_per_window, (const Aff<C>*)salts, win_out, slabs);
+                }
+            } else if (one_wave) {
                 hipLaunchKernelGGL((msm_wave_reduce_kernel<C, 1>), dim3((nb1 + wpb - 1) / wpb), dim3(64 * wpb), lds_wave * wpb, st,
                                    i0, none, none, nb1, 1u, segs_per_window, L1, (const Aff<C>*)salts, seg_out, slabs);
                 hipLaunchKernelGGL((msm_wave_reduce_kernel<C, 1>), dim3((nb2 + wpb - 1) / wpb), dim3(64 * wpb), lds_wave * wpb, st,
@@ -838,9 +876,9 @@ struct MsmJob {
             }
         }
         HIPCHK(hipGetLastError());
-        HIPCHK(hipEventRecord(g.pev[slot][5], st));
+        HIPCHK(hipEventRecord(g.pev[es][5], st));
         HIPCHK(hipMemcpyAsync(hw, win_out, (size_t)9 * RW * sizeof(Proj<C>), hipMemcpyDeviceToHost, st));
-        HIPCHK(hipEventRecord(g.pev[slot][6], st));
+        HIPCHK(hipEventRecord(g.pev[es][6], st));
         return GH_OK;
     }
 
@@ -852,9 +890,19 @@ struct MsmJob {
             g.batch_tm.push_back(g.last_msm);
             return GH_OK;
         }
-        HIPCHK(hipEventSynchronize(g.pev[slot][6]));
+        HIPCHK(hipEventSynchronize(g.pev[es][6]));
         auto t_fold0 = std::chrono::steady_clock::now();
         std::vector<Proj<C>> hwv(hw, hw + (size_t)9 * RW);
+        if (lean) {
+            // level 2 wrote (T_w, A2, Bv2) for the lanes' run and PA' = sum of the lanes' wacc:
+            //   R_w = 64 PA' + 64 L1 A2 + Bv2   ->   the fold's slots PW = 0, PS = A2 (weight 2^u = 64 L1), PA = PA', PB = Bv2
+            for (int w = 0; w < RW; w++) {
+                const Proj<C> t = hw[(size_t)w * 3], a2 = hw[(size_t)w * 3 + 1], bv2 = hw[(size_t)w * 3 + 2], pa = hw[(size_t)(RW + w) * 3];
+                hwv[(size_t)w * 3] = t; hwv[(size_t)w * 3 + 1] = proj_zero<C>(); hwv[(size_t)w * 3 + 2] = a2;
+                hwv[(size_t)(RW + w) * 3] = pa;
+                hwv[(size_t)(2 * RW + w) * 3] = bv2;
+            }
+        }
         // Window sum R_w = 64 PA + PB + U (64 PW + PS), U = 64 L1 = 2^u, with
         //   PW, PS = (A, Bv) of the weighted level-2 program over the runW's, PA = sum A, PB = sum Bv.
         // Horner over windows, high to low (variable_base.rs:73-82), with the powers of two of R_w
@@ -870,10 +918,10 @@ struct MsmJob {
             fold_windows<C>(hwv, W, c, u, sw, top_unsigned, out_xyz);
         }
         auto t_end = std::chrono::steady_clock::now();
-        HIPCHK(hipEventElapsedTime(&tm.sort_ms, g.pev[slot][0], g.pev[slot][1]));
-        HIPCHK(hipEventElapsedTime(&tm.accumulate_ms, g.pev[slot][2], g.pev[slot][3]));   // brackets exactly the accumulation launch
-        HIPCHK(hipEventElapsedTime(&tm.heavy_ms, g.pev[slot][3], g.pev[slot][4]));
-        HIPCHK(hipEventElapsedTime(&tm.reduce_ms, g.pev[slot][4], g.pev[slot][5]));
+        HIPCHK(hipEventElapsedTime(&tm.sort_ms, g.pev[es][0], g.pev[es][1]));
+        HIPCHK(hipEventElapsedTime(&tm.accumulate_ms, g.pev[es][2], g.pev[es][3]));   // brackets exactly the accumulation launch
+        HIPCHK(hipEventElapsedTime(&tm.heavy_ms, g.pev[es][3], g.pev[es][4]));
+        HIPCHK(hipEventElapsedTime(&tm.reduce_ms, g.pev[es][4], g.pev[es][5]));
         tm.heavy_buckets = n_heavy;
         tm.fold_ms = std::chrono::duration<float, std::milli>(t_end - t_fold0).count();
         tm.total_ms = std::chrono::duration<float, std::milli>(t_end - t_begin).count();
@@ -915,8 +963,11 @@ int accumulate_lists(const void* points, const uint32_t* sorted, const uint32_t*
 // buffer slots: while MSM k accumulates (stream_acc), the bucket sort of MSM k+1 (g.stream) and the
 // bucket reduction + host fold of MSM k-1 (stream_red, host) run beside it -- the sort is
 // atomics/memory bound and the reduction's wave programs are latency chains, so both fit into the
-// issue slots the accumulation leaves.  Slot reuse is ordered by events:
+// issue slots the accumulation leaves.  Slot reuse is ordered by events (one event set per job in flight, g.pev[k & 3]):
 //   sort(k+1) waits for acc(k-1) (lists of that slot), acc(k+1) for reduce(k-1) (its buckets).
+// Not free: leaving the reduction out of a batch (measurement only) takes the 2^20-pair G1 MSM from 23.4 to 20.1 ms -- the
+// reduction's instructions are issued at the accumulation's expense.  Hence the lean form of the reduction for the MSMs
+// of a batch that have a successor to hide its longer chain behind (MsmJob::prepare).
 template <class C>
 int msm_batch(BasesBase* const* hs, const void* const* d_scalars, const size_t* n_scalars, int count, uint64_t* out_xyz) {
     const size_t out_stride = (size_t)36 * C::F::DEG;
@@ -925,9 +976,11 @@ int msm_batch(BasesBase* const* hs, const void* const* d_scalars, const size_t* 
     auto issue_sort = [&](int k) -> int {
         MsmJob<C>& j = jobs[(size_t)k];
         j.solo = count == 1;
+        j.last = k == count - 1;
+        j.es = k & 3;
         if ((rc = j.prepare(hs[k], d_scalars[k], n_scalars[k], out_xyz + (size_t)k * out_stride, k & 1))) return rc;
         if (k >= 2) {
-            HIPCHK(hipStreamWaitEvent(g.stream, g.pev[k & 1][4], 0));   // acc(k-2) has consumed this slot's lists
+            HIPCHK(hipStreamWaitEvent(g.stream, g.pev[(k - 2) & 3][4], 0));   // acc(k-2) has consumed this slot's lists
         }
         return j.launch_sort(g.stream);
     };
@@ -936,14 +989,16 @@ int msm_batch(BasesBase* const* hs, const void* const* d_scalars, const size_t* 
     if ((rc = issue_sort(0))) return rc;
     for (int k = 0; k < count; k++) {
         MsmJob<C>& j = jobs[(size_t)k];
-        if (k >= 2 && j.n) HIPCHK(hipStreamWaitEvent(g.stream_acc, g.pev[k & 1][6], 0));   // reduce(k-2) is done with this slot's buckets
+        if (k >= 2 && j.n) HIPCHK(hipStreamWaitEvent(g.stream_acc, g.pev[(k - 2) & 3][6], 0));   // reduce(k-2) is done with this slot's buckets
         if ((rc = j.launch_accumulate(g.stream_acc))) return rc;
-        if (j.n) HIPCHK(hipStreamWaitEvent(g.stream_red, g.pev[k & 1][4], 0));
+        if (j.n) HIPCHK(hipStreamWaitEvent(g.stream_red, g.pev[k & 3][4], 0));
         if ((rc = j.launch_reduce(g.stream_red))) return rc;
-        // finish(k-1) before sort(k+1): they share a slot (stage events, pinned buffers).  The host waits
-        // here for reduce(k-1), a few ms into acc(k); sort(k+1) still has most of acc(k) to hide behind.
-        if (k >= 1 && (rc = jobs[(size_t)k - 1].finish())) return rc;
+        // sort(k+1) goes out before the host waits for the window sums of k-1: the two share a buffer slot but no buffer
+        // (lists and plan of the slot were consumed by acc(k-1); buckets, segment sums and the pinned window sums are the
+        // reduction's) and, since round 3, no events -- so the sort of the next MSM no longer starts only when the
+        // reduction of the previous one has ended (11 ms into acc(k), more with the lean reduction's longer chain).
         if (k + 1 < count && (rc = issue_sort(k + 1))) return rc;
+        if (k >= 1 && (rc = jobs[(size_t)k - 1].finish())) return rc;
     }
     return jobs[(size_t)count - 1].finish();
 }

@@ -1160,6 +1160,9 @@ msm_heavy_combine_kernel(const Proj<C>* __restrict__ partials, const uint32_t* _
 //   6 steps           tree over lanes l >= 1 of S                -> Bv = sum_l l * run_l
 // With item index = l + 64 i:   sum_items index * x = 64 * A + Bv,  sum_items x = runW.
 // mode 1 (plain sum) stops after the serial part and a tree over run.
+// mode 2 ("lean" level 1, msm_impl.h) stops after the serial part and stores every lane's (run_l, wacc_l) -- out[(program * 64
+// + l) * 2 + {0, 1}] -- for a second level that works on LANES instead of segments: the 18 cross-lane steps, in which most
+// lanes idle, are then issued once per window instead of once per segment.
 // Equal operands (acc == x as points, the reference's doubling branch) are detected in the
 // addition; the whole wave then spends three extra steps on a detour through a salt point
 // (p + S) + q - S for the affected lanes.  Powers of two (64, 64 L) that weight the outputs are
@@ -1291,7 +1294,10 @@ msm_wave_reduce_kernel(WaveReduceIn<C> in0, WaveReduceIn<C> in1, WaveReduceIn<C>
     const uint32_t w = blk / segs_per_window, seg = blk % segs_per_window;
     const uint32_t item0 = seg * 64u * (uint32_t)L;
     if ((size_t)w * in.count + item0 >= (size_t)in.valid) {   // segment of padding slots only: all sums are infinity
-        if (lane == 0) {
+        if (in.mode == 2) {
+            const Proj<C> z = proj_zero<C>();
+            st_proj<C>(out + ((size_t)blk * 64 + lane) * 2, z); st_proj<C>(out + ((size_t)blk * 64 + lane) * 2 + 1, z);
+        } else if (lane == 0) {
             Proj<C>* oz = out + ((size_t)which * blocks_per_input + blk) * 3;
             const Proj<C> z = proj_zero<C>();
             st_proj<C>(oz, z); st_proj<C>(oz + 1, z); st_proj<C>(oz + 2, z);
@@ -1299,7 +1305,7 @@ msm_wave_reduce_kernel(WaveReduceIn<C> in0, WaveReduceIn<C> in1, WaveReduceIn<C>
         return;
     }
     const int NS1 = in.mode == 1 ? L : 2 * L - 1;
-    const int NST = in.mode == 1 ? L + 6 : NS1 + 18;
+    const int NST = in.mode == 1 ? L + 6 : (in.mode == 2 ? NS1 : NS1 + 18);
     uint32_t* slab = slabs + (size_t)gb * SL::WORDS;
     {
         const Proj<C> z = proj_zero<C>();
@@ -1388,7 +1394,10 @@ msm_wave_reduce_kernel(WaveReduceIn<C> in0, WaveReduceIn<C> in1, WaveReduceIn<C>
             if (det == 3) { det = 0; mydet = false; step++; } else det++;
         }
     }
-    if (lane == 0) {
+    if (in.mode == 2) {
+        st_proj<C>(out + ((size_t)blk * 64 + lane) * 2, SL::ld(slab, RUN, lane));
+        st_proj<C>(out + ((size_t)blk * 64 + lane) * 2 + 1, SL::ld(slab, WACC, lane));
+    } else if (lane == 0) {
         if (in.mode == 1) {
             st_proj<C>(o, SL::ld(slab, RUN, lane));
         } else {

@@ -36,7 +36,7 @@ struct Ctx {
     hipStream_t stream_acc = nullptr;   // MSM accumulation (lowest priority: the filler of the pipeline)
     hipStream_t stream_red = nullptr;   // MSM bucket reduction (highest priority: short latency chains)
     hipEvent_t ev[8];
-    hipEvent_t pev[2][8];               // MSM stage events per pipeline slot
+    hipEvent_t pev[4][8];               // MSM stage events, one set per job in flight (job k of a batch uses set k & 3)
     std::map<int, Domain> domains[2];
     std::map<std::string, DevBuf> pool;
     int window_override = 0;

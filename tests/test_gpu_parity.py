@@ -643,3 +643,20 @@ def test_msm_cached_is_a_pure_function_of_its_arguments(gpu):
     gpu.key_cache_config()
     gpu.key_cache_clear()
     assert gpu.key_cache_stats()["entries"] == 0
+
+
+def test_msm_parity_again_with_the_lean_reduction_forced(gpu):
+    """Inside a pipelined batch of large MSMs the bucket reduction runs in its lane-level form (msm_impl.h: `lean`; level 1 hands
+    every lane's two sums to level 2).  Sizes the oracle can referee never reach it by themselves, so the MSM parity tests of
+    this file run once more in a child process with GH_REDUCE_LEAN=1 (the switch is read once per process): every curve's G1
+    path, all window regimes, skewed scalars, heavy buckets, resident keys and batches -- against the oracle as before."""
+    import os, subprocess, sys
+    if os.environ.get("GH_REDUCE_LEAN"):
+        pytest.skip("already the forced run")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GH_REDUCE_LEAN="1")
+    sel = "test_msm_golden or test_msm_vs_oracle or test_msm_window_sizes_vs_oracle or test_msm_unequal_lengths_and_resident or test_msm_skewed_scalars"
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-m", "gpu", "-x", "-q", "-k", sel],
+                         env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert " passed" in out.stdout
