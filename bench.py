@@ -344,7 +344,11 @@ def main():
                        "2^%d" % (n.bit_length() - 1) if n & (n - 1) == 0 else str(n),
                        " (2^%d in all, strong scaling)" % args.total_log_n if strong else ""),
                    "curve": curve, "pairs_per_gpu": n, "window_bits": tm_last["window_bits"], "num_windows": tm_last["num_windows"],
-                   "resident_key_shift_table": table_info, "distinct_bases": n, "bucket_sums": bucket_mode, "parallelism": "pairs sharded by rank, 1 all-gather of partial sums" if world > 1 else "single GPU"},
+                   "resident_key_shift_table": table_info, "distinct_bases": n, "bucket_sums": bucket_mode,
+                   "bucket_reduction": ("segment form (GH_REDUCE_LEAN=0)" if os.environ.get("GH_REDUCE_LEAN") == "0" else
+                                        "lean (lane-level) form for every MSM of the batch but the last, from 2^25 list entries; segment form otherwise")
+                                       if (C.deg == 1 and not args.no_pipeline) else "segment form",
+                   "parallelism": "pairs sharded by rank, 1 all-gather of partial sums" if world > 1 else "single GPU"},
         "closed_form_ok": cf_ok,
         "closed_form_note": "each rank's partial sum of the last timed step == (sum s_i) P_0 + (sum i s_i) H on its chain key, evaluated with "
                             "Python integers (tests/support.py chain_msm_closed_form): an answer no MSM code path produced",
