@@ -416,6 +416,10 @@ struct KeyCache {
     int table_after = 2;                      // build the shift table at this sighting (0 = never)
     gh_key_cache_stats_t st{};
     bool registered = false;
+    // the scalars of the call in progress: the cache's OWN buffer, not a pool buffer -- the copy into it runs while this thread
+    // hashes, uploads or builds a shift table, and the table builder may drop every pool buffer to make room (pool_release)
+    void* d_scal = nullptr;
+    size_t scal_cap = 0;
 };
 KeyCache kc;
 size_t key_bytes(const BasesBase* h) {
@@ -505,8 +509,12 @@ int gh_msm_cached(gh_curve_t curve, const uint64_t* bases, const uint8_t* infini
     std::thread uploader;
     struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{uploader};
     if (n > 0) {
-        rc = pool_get("scalars", n * 96, &d_s);
-        if (rc) return rc;
+        if (kc.scal_cap < n * 96) {
+            if (kc.d_scal) { HIPCHK(hipFree(kc.d_scal)); kc.d_scal = nullptr; kc.scal_cap = 0; }
+            HIPCHK(hipMalloc(&kc.d_scal, n * 96 + 256));
+            kc.scal_cap = n * 96;
+        }
+        d_s = kc.d_scal;
         const int dev = g.device;
         hipStream_t st = g.stream;
         uploader = std::thread([=, &up_err] {
@@ -518,7 +526,12 @@ int gh_msm_cached(gh_curve_t curve, const uint64_t* bases, const uint8_t* infini
     const KeyHash hh = content_hash(curve, bases, infinity, n);
     if (!kc.registered) {
         kc.registered = true;
-        g.at_shutdown.push_back([] { cache_drop_all(); kc.registered = false; });
+        g.at_shutdown.push_back([] {
+            cache_drop_all();
+            if (kc.d_scal) (void)hipFree(kc.d_scal);
+            kc.d_scal = nullptr; kc.scal_cap = 0;
+            kc.registered = false;
+        });
     }
     CachedKey* hit = nullptr;
     for (auto& k : kc.e) if (k.curve == curve && k.n == n && k.h.a == hh.a && k.h.b == hh.b) { hit = &k; break; }
