@@ -645,52 +645,6 @@ def test_msm_cached_is_a_pure_function_of_its_arguments(gpu):
     assert gpu.key_cache_stats()["entries"] == 0
 
 
-def test_msm_cached_when_the_table_builder_drops_the_scratch_pool(gpu):
-    """gh_msm_cached copies its scalars to the device while it hashes the bases -- and at the second sighting the shift-table
-    builder, short of memory, drops every pooled scratch buffer before it gives up (msm_impl.h: precompute_bases ->
-    pool_release).  The scalars therefore live in a buffer of the cache's own (a pooled one was freed under the running copy:
-    the 2^22-pair G2 bench line faulted on it).  Here the card is filled up to 600 MB, the second sighting cannot build its
-    table, and the sum must still be the oracle's."""
-    curve = "mnt4753_g1"
-    C = pyref.CURVES[curve]
-    n = 1 << 13
-    b, _ = S.bases_array(C, S.chain_points(C, n, pyref.Rng(5)))
-    s1 = S.random_scalars_np(n, seed=81, below=C.order)
-    s2 = S.random_scalars_np(n, seed=82, below=C.order)
-
-    def aff(x):
-        xy, inf = gpu.proj_to_affine(curve, x)
-        return inf, xy.tobytes()
-
-    def oaff(s):
-        xy, inf = S.oracle_affine(curve, S.oracle_msm(curve, b, None, s, 16))
-        return inf, xy.tobytes()
-
-    gpu.key_cache_clear()
-    gpu.key_cache_config(64 << 30, 2)
-    base = gpu.key_cache_stats()
-    assert aff(gpu.msm_cached(curve, b, s1)) == oaff(s1)
-    gpu.dev_trim()
-    hogs = []
-    for size in (16 << 30, 1 << 30, 128 << 20):                              # fill the card: 16 GB, 1 GB, 128 MB blocks until each size fails
-        while True:
-            try:
-                hogs.append(gpu.DeviceBuffer(size))
-            except Exception:
-                break
-    for _ in range(5):                                                         # ... and give 640 MB back
-        hogs.pop().free()
-    try:
-        assert aff(gpu.msm_cached(curve, b, s2)) == oaff(s2)                    # second sighting: no room for the table
-        st = gpu.key_cache_stats()
-        assert st["tables_built"] == base["tables_built"] and st["hits"] - base["hits"] == 1
-        assert aff(gpu.msm_cached(curve, b, s1)) == oaff(s1)
-    finally:
-        for h in hogs:
-            h.free()
-        gpu.key_cache_clear()
-
-
 def test_msm_parity_again_with_the_lean_reduction_forced(gpu):
     """Inside a pipelined batch of large MSMs the bucket reduction runs in its lane-level form (msm_impl.h: `lean`; level 1 hands
     every lane's two sums to level 2).  Sizes the oracle can referee never reach it by themselves, so the MSM parity tests of
