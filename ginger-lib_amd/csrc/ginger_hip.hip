@@ -517,11 +517,15 @@ int gh_msm_cached(gh_curve_t curve, const uint64_t* bases, const uint8_t* infini
         d_s = kc.d_scal;
         const int dev = g.device;
         hipStream_t st = g.stream;
-        uploader = std::thread([=, &up_err] {
-            hipError_t e = hipSetDevice(dev);
-            if (e == hipSuccess) e = hipMemcpyAsync(d_s, scalars, n * 96, hipMemcpyHostToDevice, st);
-            up_err = e;
-        });
+        try {
+            uploader = std::thread([=, &up_err] {
+                hipError_t e = hipSetDevice(dev);
+                if (e == hipSuccess) e = hipMemcpyAsync(d_s, scalars, n * 96, hipMemcpyHostToDevice, st);
+                up_err = e;
+            });
+        } catch (...) {      // no thread to be had: the copy goes first, the hash after it
+            HIPCHK(hipMemcpyAsync(d_s, scalars, n * 96, hipMemcpyHostToDevice, st));
+        }
     }
     const KeyHash hh = content_hash(curve, bases, infinity, n);
     if (!kc.registered) {
