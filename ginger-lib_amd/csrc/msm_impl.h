@@ -198,17 +198,17 @@ int precompute_bases(BasesBase* h, int c_req) {
     for (size_t i0 = 0; i0 < n && e == hipSuccess; i0 += slab) {
         const size_t cnt = n - i0 < slab ? n - i0 : slab;
         static const bool pre_jac = !(getenv("GH_PRE_JAC") && atoi(getenv("GH_PRE_JAC")) == 0);
-        bool done = false;
-        if constexpr (C::F::DEG == 1) {
-            if (pre_jac) {
-                hipLaunchKernelGGL((msm_precompute_jac_kernel<C>), dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st,
+        if (pre_jac) {
+            if constexpr (C::F::DEG == 1)
+                hipLaunchKernelGGL((msm_precompute_jac_kernel<C, typename C::F>), dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st,
                                    table, (const uint8_t*)h->d_inf, n, i0, cnt, slab, c, W, zs, zp, bad);
-                done = true;
-            }
-        }
-        if (!done)
+            else
+                hipLaunchKernelGGL((msm_precompute_jac_kernel<C, typename C::FC>), dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, st,
+                                   table, (const uint8_t*)h->d_inf, n, i0, cnt, slab, c, W, zs, zp, bad);
+        } else {
             hipLaunchKernelGGL((msm_precompute_kernel<C>), dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, st,
                                table, (const uint8_t*)h->d_inf, n, i0, cnt, slab, c, W, zs, zp, bad);
+        }
         e = hipGetLastError();
     }
     uint32_t hbad = 0;

@@ -215,16 +215,16 @@ msm_precompute_kernel(Aff<C>* __restrict__ table, const uint8_t* __restrict__ in
     }
 }
 
-// The same table for the prime-field curves (G1) with the doublings in JACOBIAN coordinates and the field products inlined
-// (round 3): dbl-2007-bl is 1 M + 8 S + a ZZ^2 against the 5 M + 6 S of the homogeneous doubling above, whose twelve products
-// are out-of-line calls at that -- 2^20 bases, c = 21: 0.83 -> 0.3x s.  Row w holds (X, Y) of 2^(c w) P until the backward
+// The same table with the doublings in JACOBIAN coordinates (round 3): dbl-2007-bl is 1 M + 8 S + a ZZ^2 against the 5 M + 6 S of
+// the homogeneous doubling above; for the prime-field curves (G1) the products are inlined as well, where the kernel above
+// calls them out of line -- 2^20 G1 bases, c = 21: 0.85 -> 0.40 s.  Row w holds (X, Y) of 2^(c w) P until the backward
 // sweep turns them into x = X / Z^2, y = Y / Z^3 with ONE inversion per base over the row Z's (Montgomery's trick, as above).
-template <class C>
-__global__ void __launch_bounds__(256, 2)
+template <class C, class F>
+__global__ void __launch_bounds__(F::DEG == 1 ? 256 : 64)
 msm_precompute_jac_kernel(Aff<C>* __restrict__ table, const uint8_t* __restrict__ infinity, size_t n, size_t i0, size_t cnt,
-                          size_t slab, int c, int W, Fp* __restrict__ zs, Fp* __restrict__ zp, uint32_t* __restrict__ bad) {
-    typedef typename C::PF P;
-    static_assert(C::F::DEG == 1, "Jacobian table builder: prime-field curves");
+                          size_t slab, int c, int W, typename F::T* __restrict__ zs, typename F::T* __restrict__ zp,
+                          uint32_t* __restrict__ bad) {
+    typedef typename F::T T;          // F: the inlined prime field for G1, the out-of-line towers for G2 (same formulas)
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= cnt) return;
     const size_t i = i0 + t;
@@ -233,34 +233,34 @@ msm_precompute_jac_kernel(Aff<C>* __restrict__ table, const uint8_t* __restrict_
         for (int w = 1; w < W; w++) st_words(table + (size_t)w * n + i, b);
         return;
     }
-    Fp X = b.x, Y = b.y, Z = fp_one<P>(), run = fp_one<P>();
+    T X = b.x, Y = b.y, Z = F::one(), run = F::one();
     for (int w = 1; w < W; w++) {
 #pragma nounroll
         for (int d = 0; d < c; d++) {
-            const Fp xx = fp_sqr<P>(X), yy = fp_sqr<P>(Y), zz = fp_sqr<P>(Z);
-            const Fp yyyy = fp_sqr<P>(yy);
-            const Fp s = fp_dbl<P>(fp_sub<P>(fp_sub<P>(fp_sqr<P>(fp_add<P>(X, yy)), xx), yyyy));
-            const Fp m = fp_add<P>(fp_add<P>(fp_dbl<P>(xx), xx), C::mul_by_a(fp_sqr<P>(zz)));
-            const Fp z3 = fp_sub<P>(fp_sub<P>(fp_sqr<P>(fp_add<P>(Y, Z)), yy), zz);
-            X = fp_sub<P>(fp_sqr<P>(m), fp_dbl<P>(s));
-            Y = fp_sub<P>(fp_mul<P>(m, fp_sub<P>(s, X)), fp_dbl<P>(fp_dbl<P>(fp_dbl<P>(yyyy))));
+            const T xx = F::sqr(X), yy = F::sqr(Y), zz = F::sqr(Z);
+            const T yyyy = F::sqr(yy);
+            const T s = F::dbl(F::sub(F::sub(F::sqr(F::add(X, yy)), xx), yyyy));
+            const T m = F::add(F::add(F::dbl(xx), xx), C::mul_by_a(F::sqr(zz)));
+            const T z3 = F::sub(F::sub(F::sqr(F::add(Y, Z)), yy), zz);
+            X = F::sub(F::sqr(m), F::dbl(s));
+            Y = F::sub(F::mul(m, F::sub(s, X)), F::dbl(F::dbl(F::dbl(yyyy))));
             Z = z3;
         }
-        if (fp_is_zero(Z)) { atomicOr(bad, 1u); return; }
+        if (F::is_zero(Z)) { atomicOr(bad, 1u); return; }
         st_words(table + (size_t)w * n + i, Aff<C>{X, Y});
         st_words(zs + (size_t)(w - 1) * slab + t, Z);
-        run = fp_mul<P>(run, Z);
+        run = F::mul(run, Z);
         st_words(zp + (size_t)(w - 1) * slab + t, run);
     }
-    Fp inv = dev_fp_inv<P>(run);   // 1 / (Z_1 ... Z_(W-1))
+    T inv = DevInv<F>::inv(run);   // 1 / (Z_1 ... Z_(W-1))
     for (int w = W - 1; w >= 1; w--) {
-        Fp zi = inv;
-        if (w > 1) zi = fp_mul<P>(inv, ld_words(zp + (size_t)(w - 2) * slab + t));   // 1 / Z_w
-        inv = fp_mul<P>(inv, ld_words(zs + (size_t)(w - 1) * slab + t));
+        T zi = inv;
+        if (w > 1) zi = F::mul(inv, ld_words(zp + (size_t)(w - 2) * slab + t));   // 1 / Z_w
+        inv = F::mul(inv, ld_words(zs + (size_t)(w - 1) * slab + t));
         Aff<C> q = ld_words(table + (size_t)w * n + i);
-        const Fp zi2 = fp_sqr<P>(zi);
-        q.x = fp_mul<P>(q.x, zi2);
-        q.y = fp_mul<P>(q.y, fp_mul<P>(zi2, zi));
+        const T zi2 = F::sqr(zi);
+        q.x = F::mul(q.x, zi2);
+        q.y = F::mul(q.y, F::mul(zi2, zi));
         st_words(table + (size_t)w * n + i, q);
     }
 }
