@@ -780,6 +780,10 @@ msm_accumulate_xyzz_kernel(const Aff<C>* __restrict__ bases, const uint32_t* __r
     };
 #define GH_FENCE() __builtin_amdgcn_sched_barrier(0)
     Fp zz = fp_zero(), zzz = fp_zero();
+    // The parked ordinate is V = sigma Y, sigma = -1 while `sneg`: the dual product below then needs no negated operand --
+    // with W = sigma R = (sigma q.y) ZZZ - V:  W (X3 - Q) + V PPP = -sigma Y3, so sigma flips with every update and is absorbed
+    // by the sign the incoming point gets anyway (one 26-limb negation less per update).
+    bool sneg = false;
     uint32_t k = 0;
     int phase = 0, salt_id = 0;     // phase 0: list entry k; 1: +S; 2: entry k again; 3: -S
     uint32_t guard = 0;
@@ -788,17 +792,18 @@ msm_accumulate_xyzz_kernel(const Aff<C>* __restrict__ bases, const uint32_t* __r
         Fp qx, qy;
         if (phase == 1 || phase == 3) {
             const Aff<C> s = ld_aff<C>(salts + salt_id);
-            qx = s.x; qy = phase == 3 ? fp_neg<P>(s.y) : s.y;
+            qx = s.x; qy = ((phase == 3) != sneg) ? fp_neg<P>(s.y) : s.y;
         } else {
             if constexpr (AFFIN) {
                 const uint32_t e = beg + k;
                 qx = t64_ld_x(bases, e >> 6, e & 63u);
                 qy = t64_ld_y(bases, e >> 6, e & 63u);
                 if (phase == 0 && qx.l[0] == AFF_MARK) { k++; continue; }   // a cancelled pair: nothing to add
+                if (sneg) qy = fp_neg<P>(qy);
             } else {
                 const uint32_t e = sorted[beg + k];
                 const Aff<C> b = ld_aff<C>(bases + (e & 0x7FFFFFFFu));
-                qx = b.x; qy = (e >> 31) ? fp_neg<P>(b.y) : b.y;
+                qx = b.x; qy = (((e >> 31) != 0) != sneg) ? fp_neg<P>(b.y) : b.y;
             }
         }
         if (fp_is_zero(zz)) {
@@ -810,7 +815,7 @@ msm_accumulate_xyzz_kernel(const Aff<C>* __restrict__ bases, const uint32_t* __r
             Fp r = fp_mul<P>(qy, zzz);                              // S2
             GH_FENCE();
             pp = fp_sub<P>(pp, get(0));                             // P = U2 - X1
-            r = fp_sub<P>(r, get(1));                               // R = S2 - Y1
+            r = fp_sub<P>(r, get(1));                               // W = sigma (S2 - Y1) = sigma R
             if (phase == 0 && fp_is_zero(pp) && fp_is_zero(r)) {    // acc == q: the detour (swp.rs:492-495 doubles here)
                 salt_id = fp_eq(qx, ld_aff<C>(salts).x) ? 1 : 0;
                 phase = 1;
@@ -830,11 +835,10 @@ msm_accumulate_xyzz_kernel(const Aff<C>* __restrict__ bases, const uint32_t* __r
             Fp x3 = fp_sub<P>(fp_sub<P>(fp_sqr<P>(r), pp), fp_dbl<P>(p2));
             put(0, x3);
             GH_FENCE();
-            p2 = fp_sub<P>(p2, x3);                                 // Q - X3
+            p2 = fp_sub<P>(x3, p2);                                 // X3 - Q
             GH_FENCE();
-            const Fp ny = fp_neg<P>(get(1));
-            GH_FENCE();
-            put(1, fp_mul2s<P>(r, p2, ny, pp));                     // Y3 = R (Q - X3) - Y1 PPP
+            put(1, fp_mul2s<P>(r, p2, get(1), pp));                 // W (X3 - Q) + V PPP = -sigma Y3: the new V, sigma flips
+            sneg = !sneg;
             GH_FENCE();
         }
         if (phase == 0 || phase == 3) { k++; phase = 0; } else phase++;
@@ -843,7 +847,7 @@ msm_accumulate_xyzz_kernel(const Aff<C>* __restrict__ bases, const uint32_t* __r
     Proj<C> out = proj_zero<C>();
     if (!fp_is_zero(zz)) {
         out.x = fp_mul<P>(get(0), zzz);
-        out.y = fp_mul<P>(get(1), zz);
+        out.y = fp_mul<P>(sneg ? fp_neg<P>(get(1)) : get(1), zz);
         out.z = fp_mul<P>(zz, zzz);
     }
     st_proj<C>(dst, out);
