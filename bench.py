@@ -496,6 +496,7 @@ def main():
                     g_out = rbg.msm_dev(dg, ng)
                 one_ms = (time.perf_counter() - t1) / KG * 1e3
                 gtm = gl.msm_last_timing()
+                gl.msm_batch_dev([(rbg, dg, ng)] * 2)            # untimed: the second pipeline slot's buffers are allocated on first use
                 t1 = time.perf_counter()
                 gb_out = gl.msm_batch_dev([(rbg, dg, ng)] * KG)
                 bt_ms = (time.perf_counter() - t1) * 1e3 / KG
