@@ -449,6 +449,24 @@ def main():
             t1 = time.perf_counter()
             b_out = gl.msm_batch_dev([(rb24, d24, n24)] * K24)
             bt_ms = (time.perf_counter() - t1) * 1e3 / K24
+            # partial table: 8 rows at c = 21 (28 GB where the full table above is 115 GB) -- what a prover with several 2^24-base
+            # queries can keep resident for all of them (gh_bases_precompute_rows)
+            t1 = time.perf_counter()
+            c24p = rb24.precompute(0, 8)
+            pbuild_s = time.perf_counter() - t1
+            rows24p = rb24.table_rows()
+            rb24.msm_dev(d24, n24)
+            t1 = time.perf_counter()
+            for _ in range(K24):
+                pt_out = rb24.msm_dev(d24, n24)
+            ptb_ms = (time.perf_counter() - t1) * 1e3 / K24
+            gl.msm_batch_dev([(rb24, d24, n24)] * 2)
+            t1 = time.perf_counter()
+            pb_out = gl.msm_batch_dev([(rb24, d24, n24)] * K24)
+            pbt_ms = (time.perf_counter() - t1) * 1e3 / K24
+            partial24 = {"value": n24 / ptb_ms * 1e3, "ms": ptb_ms, "window_bits": c24p, "rows": rows24p, "bytes": rows24p * n24 * 208,
+                         "build_s": pbuild_s, "pipelined_batch": {"value": n24 / pbt_ms * 1e3, "ms_per_msm": pbt_ms, "steps": K24},
+                         "closed_form_ok": closed_form_ok(curve, p0_24, st_24, s24, pt_out) and closed_form_ok(curve, p0_24, st_24, s24, pb_out[-1])}
             a0, a1 = gl.proj_to_affine(curve, p_out), gl.proj_to_affine(curve, t_out)
             cf24 = closed_form_ok(curve, p0_24, st_24, s24, b_out[-1]) and closed_form_ok(curve, p0_24, st_24, s24, p_out)
             del s24
@@ -459,7 +477,8 @@ def main():
                 "shift_table": {"value": n24 / tb_ms * 1e3, "ms": tb_ms, "window_bits": c24, "rows": 752 // c24 + 1,
                                 "bytes": (752 // c24 + 1) * n24 * 208, "build_s": build_s, "accumulate_ms": ttm["accumulate_ms"],
                                 "pipelined_batch": {"value": n24 / bt_ms * 1e3, "ms_per_msm": bt_ms, "steps": K24}},
-                "steps_per_figure": K24, "closed_form_ok": cf24,
+                "partial_table": partial24,
+                "steps_per_figure": K24, "closed_form_ok": cf24 and partial24["closed_form_ok"],
                 "roofline": {"bound": "hbm", "achieved": 288.0 * n24 / (ttm["accumulate_ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": 288.0 * n24 / (ttm["accumulate_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                              "avg_launch_ms": ttm["accumulate_ms"], "algorithmic_bytes_per_launch": 288.0 * n24},

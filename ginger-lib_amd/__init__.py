@@ -29,7 +29,7 @@ FIELDS = {"mnt4753_fr": 0, "mnt6753_fr": 1}
 # every symbol include/ginger_hip.h declares (checked by load_library and by tests/test_abi.py)
 ABI_SYMBOLS = [
     "gh_init", "gh_shutdown", "gh_last_error", "gh_device_name",
-    "gh_msm", "gh_bases_upload", "gh_bases_upload_wire", "gh_bases_generate_chain", "gh_bases_download", "gh_bases_free", "gh_bases_len", "gh_bases_precompute", "gh_bases_precomputed_window",
+    "gh_msm", "gh_bases_upload", "gh_bases_upload_wire", "gh_bases_generate_chain", "gh_bases_download", "gh_bases_free", "gh_bases_len", "gh_bases_precompute", "gh_bases_precomputed_window", "gh_bases_precompute_rows", "gh_bases_table_rows",
     "gh_msm_resident", "gh_msm_resident_dev", "gh_msm_resident_dev_batch",
     "gh_msm_cached", "gh_key_cache_config", "gh_key_cache_clear", "gh_key_cache_stats", "gh_bases_content_hash",
     "gh_msm_set_window", "gh_msm_set_affine", "gh_msm_get_window", "gh_msm_last_timing", "gh_msm_batch_timing",
@@ -90,6 +90,8 @@ def load_library():
     lib.gh_bases_len.restype = sz
     lib.gh_bases_precompute.argtypes = [vp, ci]
     lib.gh_bases_precomputed_window.argtypes = [vp]
+    lib.gh_bases_precompute_rows.argtypes = [vp, ci, ci]
+    lib.gh_bases_table_rows.argtypes = [vp]
     lib.gh_msm_resident.argtypes = [vp, vp, sz, vp]
     lib.gh_msm_resident_dev.argtypes = [vp, vp, sz, vp]
     lib.gh_msm_resident_dev_batch.argtypes = [vp, vp, vp, ci, vp]
@@ -287,10 +289,14 @@ class ResidentBases:
         _check(load_library().gh_bases_download(self.handle, int(first), int(count), _ptr(out)))
         return out
 
-    def precompute(self, window_bits=0):
-        """Build the per-key shift table (gh_bases_precompute); returns the window size used."""
-        _check(load_library().gh_bases_precompute(self.handle, int(window_bits)))
+    def precompute(self, window_bits=0, max_rows=0):
+        """Build the per-key shift table (gh_bases_precompute / gh_bases_precompute_rows: at most max_rows rows, a partial table
+        with several bucket sets); returns the window size used."""
+        _check(load_library().gh_bases_precompute_rows(self.handle, int(window_bits), int(max_rows)))
         return load_library().gh_bases_precomputed_window(self.handle)
+
+    def table_rows(self):
+        return load_library().gh_bases_table_rows(self.handle)
 
     def msm(self, scalars):
         scalars = _u64(scalars, 12)

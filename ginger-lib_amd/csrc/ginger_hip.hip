@@ -267,16 +267,22 @@ int gh_bases_free(gh_bases_t handle) {
     return GH_OK;
 }
 
-int gh_bases_precompute(gh_bases_t handle, int window_bits) {
+int gh_bases_precompute_rows(gh_bases_t handle, int window_bits, int max_rows) {
     std::lock_guard<std::mutex> lk(g_mu);
     BasesBase* h = reinterpret_cast<BasesBase*>(handle);
     if (!h || h->magic != 0x6768424au) { g_err = "bad bases handle"; return GH_E_BAD_HANDLE; }
     if (window_bits < 0 || window_bits == 1 || window_bits > 24) { g_err = "window must be 0 (auto) or in [2, 24]"; return GH_E_BAD_ARG; }
+    if (max_rows < 0) { g_err = "max_rows must be 0 (no cap) or positive"; return GH_E_BAD_ARG; }
     const MsmOps* ops = ops_of(h->curve);
     if (!ops) return GH_E_BAD_ARG;
     int rc = ensure_init();
     if (rc) return rc;
-    return ops->precompute(h, window_bits);
+    return ops->precompute(h, window_bits, max_rows);
+}
+int gh_bases_precompute(gh_bases_t handle, int window_bits) { return gh_bases_precompute_rows(handle, window_bits, 0); }
+int gh_bases_table_rows(gh_bases_t handle) {
+    BasesBase* h = reinterpret_cast<BasesBase*>(handle);
+    return (h && h->magic == 0x6768424au && h->d_table) ? h->pre_W : 0;
 }
 
 int gh_bases_precomputed_window(gh_bases_t handle) {
@@ -559,7 +565,7 @@ int gh_msm_cached(gh_curve_t curve, const uint64_t* bases, const uint8_t* infini
     hit->sightings++;
     BasesBase* key = hit->key;
     if (kc.table_after > 0 && hit->sightings == (uint32_t)kc.table_after && !key->d_table && n >= 4096) {
-        const int prc = ops->precompute(key, 0);      // optional: NOMEM / UNSUPPORTED leave the key on the per-window path
+        const int prc = ops->precompute(key, 0, 0);   // optional: NOMEM / UNSUPPORTED leave the key on the per-window path
         if (prc == GH_OK) kc.st.tables_built++;
         else (void)hipGetLastError();
         hit->bytes = key_bytes(key);

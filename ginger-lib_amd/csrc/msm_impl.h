@@ -163,14 +163,25 @@ inline int precompute_window(size_t n, int deg) {
 }
 
 template <class C>
-int precompute_bases(BasesBase* h, int c_req) {
+int precompute_bases(BasesBase* h, int c_req, int max_rows) {
     typedef typename C::FC::T FT;
-    if (h->d_table) { HIPCHK(hipFree(h->d_table)); h->d_table = nullptr; h->pre_c = h->pre_W = 0; }
+    if (h->d_table) { HIPCHK(hipFree(h->d_table)); h->d_table = nullptr; h->pre_c = h->pre_W = 0; h->pre_G = 1; }
     const size_t n = h->n;
     if (n == 0) return GH_OK;
-    const int c = c_req > 0 ? c_req : precompute_window(n, C::F::DEG);
+    // Partial table (max_rows > 0, or GH_TABLE_ROWS for every table of the process): at most that many rows, row j = 2^(c G j) P with
+    // G = ceil(windows / max_rows) bucket sets -- window w = j G + g reads row j and files into set g; the G set sums are
+    // folded with c doublings each (finish()).  For keys whose full table does not fit next to the others (four 2^24-base
+    // G1 queries: 4 x 126 GB at c = 21): 8 rows are 28 GB.  A capped table keeps its sets at 2^20 buckets (c = 21) where the
+    // full table of a large key would take c = 23: the sets multiply the bucket reduction.
+    const int env_rows = getenv("GH_TABLE_ROWS") ? atoi(getenv("GH_TABLE_ROWS")) : 0;
+    const int cap = max_rows > 0 ? max_rows : env_rows;
+    int c = c_req > 0 ? c_req : precompute_window(n, C::F::DEG);
+    if (c_req <= 0 && cap > 0 && cap < 752 / c + 1 && c > 21) c = 21;
     if (c < 2 || c > 24) { g_err = "precompute window must be in [2, 24]"; return GH_E_BAD_ARG; }
-    const int W = 752 / c + 1;
+    const int windows = 752 / c + 1;
+    const int G = cap > 0 && cap < windows ? (windows + cap - 1) / cap : 1;
+    const int W = (windows + G - 1) / G;          // rows of the table
+    const int c_row = c * G;                      // doublings from one row to the next
     if ((size_t)W * n >= ((size_t)1 << 31)) { g_err = "precomputed table too large for 31-bit entries"; return GH_E_UNSUPPORTED; }
     size_t free_b = 0, total_b = 0;
     HIPCHK(hipMemGetInfo(&free_b, &total_b));
@@ -201,13 +212,13 @@ int precompute_bases(BasesBase* h, int c_req) {
         if (pre_jac) {
             if constexpr (C::F::DEG == 1)
                 hipLaunchKernelGGL((msm_precompute_jac_kernel<C, typename C::F>), dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st,
-                                   table, (const uint8_t*)h->d_inf, n, i0, cnt, slab, c, W, zs, zp, bad);
+                                   table, (const uint8_t*)h->d_inf, n, i0, cnt, slab, c_row, W, zs, zp, bad);
             else
                 hipLaunchKernelGGL((msm_precompute_jac_kernel<C, typename C::FC>), dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, st,
-                                   table, (const uint8_t*)h->d_inf, n, i0, cnt, slab, c, W, zs, zp, bad);
+                                   table, (const uint8_t*)h->d_inf, n, i0, cnt, slab, c_row, W, zs, zp, bad);
         } else {
             hipLaunchKernelGGL((msm_precompute_kernel<C>), dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, st,
-                               table, (const uint8_t*)h->d_inf, n, i0, cnt, slab, c, W, zs, zp, bad);
+                               table, (const uint8_t*)h->d_inf, n, i0, cnt, slab, c_row, W, zs, zp, bad);
         }
         e = hipGetLastError();
     }
@@ -223,6 +234,7 @@ int precompute_bases(BasesBase* h, int c_req) {
     h->d_table = table;
     h->pre_c = c;
     h->pre_W = W;
+    h->pre_G = G;
     return GH_OK;
 }
 
@@ -300,9 +312,15 @@ void fold_windows(const std::vector<Proj<C>>& hw, int W, int c, int u, int sw, i
 // into Wp pseudo-windows of Q = 2^q slots for the two-level wave reduction; slot s = w' Q + k, so
 //   sum_s s B_s = sum_w' R_w' + Q sum_w' w' T_w'
 // with R_w' = PW 2^(u+6) + PS 2^u + PA 2^6 + PB as above and T_w' the plain sum of pseudo-window w'.
+// With a PARTIAL table the buckets form `sets` such sets (set g: the windows w = j sets + g, weight 2^(c g) on top of the
+// rows' own 2^(c sets j)): every set is folded as above over its Wp / sets pseudo-windows, then Horner over the sets.
 template <class HC>
-Proj<HC> fold_merged_generic(const std::vector<Proj<HC>>& hw, int Wp, int q, int u, int sw) {
-    auto PT = [&](int which, int w, int k) -> const Proj<HC>& { return hw[(size_t)(which * Wp + w) * 3 + k]; };
+Proj<HC> fold_merged_generic(const std::vector<Proj<HC>>& hw, int Wp_all, int q, int u, int sw, int sets, int c) {
+  Proj<HC> total_acc = proj_zero<HC>();
+  const int Wp = Wp_all / sets;
+  for (int gset = sets - 1; gset >= 0; gset--) {
+    const int w0 = gset * Wp;
+    auto PT = [&](int which, int w, int k) -> const Proj<HC>& { return hw[(size_t)(which * Wp_all + w0 + w) * 3 + k]; };
     Proj<HC> spw = proj_zero<HC>(), sps = proj_zero<HC>(), spa = proj_zero<HC>(), spb = proj_zero<HC>();
     Proj<HC> run = proj_zero<HC>(), st = proj_zero<HC>();
     for (int w = Wp - 1; w >= 0; w--) {
@@ -314,21 +332,23 @@ Proj<HC> fold_merged_generic(const std::vector<Proj<HC>>& hw, int Wp, int q, int
     }
     // slot s carries digit magnitude s + 1: sum (s + 1) B_s = sum s B_s + sum_w' T_w'   (run holds T_1 + .. + T_(Wp-1) here)
     spb = proj_add<HC>(spb, proj_add<HC>(run, PT(0, 0, 0)));
-    FoldTerm<HC> t[5] = {{u + sw, &spw}, {u, &sps}, {sw, &spa}, {0, &spb}, {q, &st}};
-    Proj<HC> acc = fold_terms<HC>(t, 5);
-    if (proj_is_zero<HC>(acc)) acc = proj_zero<HC>();
-    return acc;
+    FoldTerm<HC> t[6] = {{u + sw, &spw}, {u, &sps}, {sw, &spa}, {0, &spb}, {q, &st}, {c, &total_acc}};   // (sets above this one) * 2^c + this set
+    Proj<HC> acc = fold_terms<HC>(t, gset == sets - 1 ? 5 : 6);
+    total_acc = acc;
+  }
+    if (proj_is_zero<HC>(total_acc)) total_acc = proj_zero<HC>();
+    return total_acc;
 }
 template <class C>
-void fold_merged(const std::vector<Proj<C>>& hw, int Wp, int q, int u, int sw, uint64_t* out_xyz) {
+void fold_merged(const std::vector<Proj<C>>& hw, int Wp, int q, int u, int sw, int sets, int c, uint64_t* out_xyz) {
     typedef typename HostCurveOf<C>::type HC;
     if constexpr (HostCurveOf<C>::fast) {
         std::vector<Proj<HC>> h64(hw.size());
         for (size_t i = 0; i < hw.size(); i++) proj_to_abi_host<C>(reinterpret_cast<uint64_t*>(&h64[i]), hw[i]);
-        Proj<HC> acc = fold_merged_generic<HC>(h64, Wp, q, u, sw);
+        Proj<HC> acc = fold_merged_generic<HC>(h64, Wp, q, u, sw, sets, c);
         memcpy(out_xyz, &acc, sizeof(acc));
     } else {
-        Proj<C> acc = fold_merged_generic<C>(hw, Wp, q, u, sw);
+        Proj<C> acc = fold_merged_generic<C>(hw, Wp, q, u, sw, sets, c);
         proj_to_abi_host<C>(out_xyz, acc);
     }
 }
@@ -357,6 +377,7 @@ struct MsmJob {
     bool last = false;               // the last MSM of its batch: its reduction has nothing to hide behind
     int es = 0;                      // event set (g.pev[es]): the job's index in its batch mod 4, so that the sort of job k+1 can be
                                      // issued while job k-1 (same buffer slot) still waits for its window sums
+    int sets = 1;                    // bucket sets (window w -> set w % sets, table row w / sets)
     bool lean = false;               // bucket reduction in its lane-level form (launch_reduce)
     Proj<C>* lane_out = nullptr;
     // affine rounds (aff_kernels.h)
@@ -408,10 +429,11 @@ struct MsmJob {
         // bucket sets the reduction sees: W windows of nb slots, or (merged) RW pseudo-windows of Q slots
         const int q = 15;
         Q = merged ? (nb <= (1u << q) + 1 ? nb : (1u << q)) : nb;
-        RW = merged ? (int)((nb + Q - 1) / Q) : W;
-        total = merged ? (size_t)nb : (size_t)W * nb;          // buckets that exist
+        sets = merged ? h->pre_G : W;                          // bucket sets: 1 with a full table, pre_G with a partial one, W without
+        RW = merged ? sets * (int)((nb + Q - 1) / Q) : W;      // (merged: every set is cut into pseudo-windows of Q slots)
+        total = (size_t)sets * nb;                             // buckets that exist
         slots = (size_t)RW * Q;                                // bucket array incl. padding
-        win_stride = merged ? 0u : nb;
+        win_stride = nb;
         static const int env_L1 = getenv("GH_REDUCE_L") ? atoi(getenv("GH_REDUCE_L")) : 0;
         // items per lane, level 1 (power of two).  The wave programs are latency chains (2 L1 + 17 steps,
         // then 2 L2 + 17): as long as the launch stays within one wave per SIMD (1024 on MI355X) a shorter
@@ -463,7 +485,7 @@ struct MsmJob {
         // (2 waves / SIMD), so a bucket of s entries is free as long as s * 78 us stays well inside the
         // kernel's own duration (~ W n / 1.65e9 s); beyond that it would be the tail, and is split.
         // (merged windows: at least twice the mean bucket W n / 2^(c-1), so that chunking stays the exception)
-        heavy_thr = merged ? (uint32_t)((2 * (size_t)W * n) >> (c - 1)) : (uint32_t)((4 * n) >> (c - 1));
+        heavy_thr = merged ? (uint32_t)(((2 * (size_t)W * n) / (size_t)sets) >> (c - 1)) : (uint32_t)((4 * n) >> (c - 1));
         {
             const uint32_t by_duration = (uint32_t)((double)W * (double)n * 3.1e-6);
             if (heavy_thr < by_duration) heavy_thr = by_duration;
@@ -532,6 +554,7 @@ struct MsmJob {
             MsmPartArgs a;
             a.digits = digits; a.entries = entries; a.n = n;
             a.win_stride = win_stride; a.row_stride = merged ? (uint32_t)h->n : 0u; a.slot_shift = merged ? 1u : 0u;
+            a.sets = (uint32_t)sets;
             a.bin_shift = bin_shift; a.n_bins = (uint32_t)((total + ((size_t)1 << bin_shift) - 1) >> bin_shift);
             a.tile = tile; a.n_blocks = (uint32_t)((entries + tile - 1) / tile);
             const size_t cells = (size_t)a.n_bins * a.n_blocks + 1;
@@ -546,7 +569,7 @@ struct MsmJob {
             if ((rc = pool_get(nm, entries * 8, (void**)&part))) return rc;
             hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
                                (const uint32_t*)d_scalars, (const uint8_t*)h->d_inf, n, c, W, win_stride, top_unsigned, scalar_modulus<C>(), digits,
-                               (uint32_t*)nullptr, agg_iters, merged ? 1u : 0u);
+                               (uint32_t*)nullptr, agg_iters, merged ? 1u : 0u, (uint32_t)sets);
             HIPCHK(hipMemsetAsync(block_hist + (cells - 1), 0, 4, st));
             hipLaunchKernelGGL(msm_part_hist_kernel, dim3(a.n_blocks), dim3(MSM_PART_THREADS), 0, st, a, block_hist);
             HIPCHK(hipGetLastError());
@@ -560,7 +583,7 @@ struct MsmJob {
             HIPCHK(hipMemsetAsync(counts, 0, total * 4, st));
             hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
                                (const uint32_t*)d_scalars, (const uint8_t*)h->d_inf, n, c, W, win_stride, top_unsigned, scalar_modulus<C>(), digits, counts, agg_iters,
-                               merged ? 1u : 0u);
+                               merged ? 1u : 0u, (uint32_t)sets);
             HIPCHK(hipGetLastError());
             if ((rc = device_scan(counts, starts, total, "scan_tmp", st))) return rc;
             HIPCHK(hipMemcpyAsync(cursor, starts, total * 4, hipMemcpyDeviceToDevice, st));
@@ -572,7 +595,8 @@ struct MsmJob {
                            (const uint32_t*)order, (const uint32_t*)starts, (uint32_t)total, heavy_chunk, chunk_start, plan);
         if (!use_part)
             hipLaunchKernelGGL(msm_scatter_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)W), dim3(256), 0, st,
-                               (const int32_t*)digits, n, W, win_stride, merged ? (uint32_t)h->n : 0u, cursor, sorted, agg_iters, merged ? 1u : 0u);
+                               (const int32_t*)digits, n, W, win_stride, merged ? (uint32_t)h->n : 0u, cursor, sorted, agg_iters, merged ? 1u : 0u,
+                               (uint32_t)sets);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(hplan, plan, 32, hipMemcpyDeviceToHost, st));
         HIPCHK(hipEventRecord(g.pev[es][1], st));
@@ -923,7 +947,7 @@ struct MsmJob {
         if (merged) {
             int lq = 0;
             while ((1u << lq) < Q) lq++;            // RW > 1 only with Q = 2^q; for RW == 1 the term is empty
-            fold_merged<C>(hwv, RW, lq, u, sw, out_xyz);
+            fold_merged<C>(hwv, RW, lq, u, sw, sets, c, out_xyz);
         } else {
             fold_windows<C>(hwv, W, c, u, sw, top_unsigned, out_xyz);
         }

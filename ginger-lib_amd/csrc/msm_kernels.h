@@ -315,7 +315,8 @@ struct MsmModulus { uint32_t w[24]; };
 static __global__ void __launch_bounds__(256)
 msm_digits_kernel(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ infinity, size_t n, int c,
                   int num_windows, uint32_t win_stride, int top_unsigned, MsmModulus r,
-                  int32_t* __restrict__ digits, uint32_t* __restrict__ counts, int agg_iters, uint32_t slot_shift) {
+                  int32_t* __restrict__ digits, uint32_t* __restrict__ counts, int agg_iters, uint32_t slot_shift,
+                  uint32_t sets /* bucket sets: window w files into set w % sets (per-window path: sets = num_windows) */) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = i < n;
     uint32_t s[25];
@@ -366,7 +367,7 @@ msm_digits_kernel(const uint32_t* __restrict__ scalars, const uint8_t* __restric
         if (skip) d = 0;
         if (valid) digits[(size_t)w * n + i] = d;
         const uint32_t mag = d < 0 ? (uint32_t)(-d) : (uint32_t)d;
-        if (counts) wave_agg_inc(counts + (size_t)w * win_stride, mag - slot_shift, d != 0, agg_iters);   // (uniform branch)
+        if (counts) wave_agg_inc(counts + (size_t)((uint32_t)w % sets) * win_stride, mag - slot_shift, d != 0, agg_iters);   // (uniform branch)
     }
 }
 
@@ -387,6 +388,7 @@ struct MsmPartArgs {
     size_t entries;        // W * n
     size_t n;
     uint32_t win_stride, row_stride, slot_shift;
+    uint32_t sets;         // window w: bucket set w % sets, table row w / sets (per-window path: sets = W; full table: 1)
     uint32_t bin_shift, n_bins, tile, n_blocks;
 };
 // entry e -> (bucket, value); returns false for a zero digit
@@ -395,8 +397,8 @@ static __device__ __forceinline__ bool msm_part_entry(const MsmPartArgs& a, size
     if (d == 0) return false;
     const uint32_t mag = d < 0 ? (uint32_t)(-d) : (uint32_t)d;
     const uint32_t i = (uint32_t)(e - w_base);
-    bucket = w * a.win_stride + (mag - a.slot_shift);
-    value = (i + w * a.row_stride) | (d < 0 ? 0x80000000u : 0u);
+    bucket = (w % a.sets) * a.win_stride + (mag - a.slot_shift);
+    value = (i + (w / a.sets) * a.row_stride) | (d < 0 ? 0x80000000u : 0u);
     return true;
 }
 static __global__ void __launch_bounds__(MSM_PART_THREADS) msm_part_hist_kernel(MsmPartArgs a, uint32_t* __restrict__ block_hist) {
@@ -567,13 +569,13 @@ static __global__ void __launch_bounds__(256)
 msm_scatter_kernel(const int32_t* __restrict__ digits, size_t n, int num_windows, uint32_t win_stride,
                    uint32_t row_stride /* 0, or the table's row length (merged windows) */,
                    uint32_t* __restrict__ cursor /* = copy of starts */, uint32_t* __restrict__ sorted, int agg_iters,
-                   uint32_t slot_shift) {
+                   uint32_t slot_shift, uint32_t sets) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     int w = blockIdx.y;
     const int32_t d = i < n ? digits[(size_t)w * n + i] : 0;
     const uint32_t mag = d < 0 ? (uint32_t)(-d) : (uint32_t)d;
-    const uint32_t pos = wave_agg_inc(cursor + (size_t)w * win_stride, mag - slot_shift, d != 0, agg_iters);
-    if (d != 0) sorted[pos] = ((uint32_t)i + (uint32_t)w * row_stride) | (d < 0 ? 0x80000000u : 0u);
+    const uint32_t pos = wave_agg_inc(cursor + (size_t)((uint32_t)w % sets) * win_stride, mag - slot_shift, d != 0, agg_iters);
+    if (d != 0) sorted[pos] = ((uint32_t)i + ((uint32_t)w / sets) * row_stride) | (d < 0 ? 0x80000000u : 0u);
 }
 
 // ---------------------------------------------------------------- 4. bucket accumulation

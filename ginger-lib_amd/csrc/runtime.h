@@ -77,7 +77,9 @@ struct BasesBase {
     void* d_points = nullptr;   // n x Aff<C>, internal layout
     uint8_t* d_inf = nullptr;   // n bytes or null
     void* d_table = nullptr;    // precomputed shift table: pre_W rows of n x Aff<C> (row w = 2^(pre_c w) P), or null
-    int pre_c = 0, pre_W = 0;
+    int pre_c = 0, pre_W = 0;   // window bits, rows of the table
+    int pre_G = 1;              // bucket sets: row j = 2^(pre_c pre_G j) P, window w = j pre_G + g reads row j and files into set g
+                                // (1 = full table, one bucket set; GH_TABLE_ROWS caps the rows: a partial table)
     uint32_t magic = 0x6768424au;
 };
 struct MsmOps {
@@ -87,7 +89,7 @@ struct MsmOps {
                 size_t n_scalars, uint64_t* out_xyz);
     int (*proj_add)(uint64_t* acc_xyz, const uint64_t* p_xyz);
     int (*to_affine)(const uint64_t* xyz, uint64_t* out_xy, uint8_t* is_infinity);
-    int (*precompute)(BasesBase* h, int window_bits);
+    int (*precompute)(BasesBase* h, int window_bits, int max_rows);
     int (*batch)(BasesBase* const* hs, const void* const* d_scalars, const size_t* n_scalars, int count, uint64_t* out_xyz);
     int (*proj_mul)(const uint64_t* p_xyz, const uint64_t* scalar12, uint64_t* out_xyz);
     int (*proj_neg)(uint64_t* xyz);

@@ -115,6 +115,14 @@ size_t gh_bases_len(gh_bases_t handle);
  * GH_E_UNSUPPORTED if a base has 2-power order (2^(c w) P = infinity has no affine form).   */
 int gh_bases_precompute(gh_bases_t handle, int window_bits);
 int gh_bases_precomputed_window(gh_bases_t handle); /* c of the table, 0 if none */
+/* The same with at most max_rows rows (a PARTIAL table, for keys whose full table does not fit next to the others: four
+ * 2^24-base G1 queries are 4 x 126 GB at c = 21, eight rows of each are 4 x 28 GB).  Row j holds 2^(c G j) P_i with
+ * G = ceil(windows / max_rows); window w = j G + g reads row j and files into bucket set g, so there are G bucket sets
+ * instead of one (or one per window), folded with c doublings each.  2^24 pairs, c = 21: full table 320 ms, 8 rows 330 ms,
+ * 4 rows 340 ms, no table 391 ms per MSM.  max_rows 0 = no cap (gh_bases_precompute); window_bits 0 = 21 for a capped table of
+ * 2^20 bases or more, the full table's choice otherwise.  Same results, same error conventions as gh_bases_precompute. */
+int gh_bases_precompute_rows(gh_bases_t handle, int window_bits, int max_rows);
+int gh_bases_table_rows(gh_bases_t handle);         /* rows of the table, 0 if none */
 /* scalars on the host */
 int gh_msm_resident(gh_bases_t handle, const uint64_t* scalars, size_t n_scalars, uint64_t* out_xyz);
 

@@ -362,6 +362,45 @@ def test_msm_precomputed_vs_oracle(gpu, curve, n, windows):
     rb.free()
 
 
+@pytest.mark.parametrize("curve,n", [("mnt4753_g1", 400), ("mnt6753_g1", 150), ("mnt4753_g2", 80), ("mnt6753_g2", 50)])
+def test_msm_partial_table_vs_oracle(gpu, curve, n):
+    """gh_bases_precompute_rows: at most max_rows rows (row j = 2^(c G j) P, G = ceil(windows / max_rows) bucket sets; window
+    w = j G + g reads row j and files into set g; the sets are folded with c doublings each).  Every (c, max_rows) below --
+    one row (= the bases themselves: one bucket set per window, like the plain path), two rows, a row count that does not
+    divide the windows, more rows than windows (= the full table) -- gives the oracle's affine sum, also on a shorter
+    scalar vector and in a pipelined batch; the degenerate inputs are those of the full-table test."""
+    C = pyref.CURVES[curve]
+    r = C.order
+    rng = pyref.Rng(777 + n)
+    pool = S.chain_points(C, min(n, 48), rng)
+    pts = [pool[i % len(pool)] for i in range(n)]
+    scal = [rng.field_elem(r) for _ in range(n)]
+    scal[:10] = [0, 1, 2, r - 1, r - 2, (r - 1) // 2, (r + 1) // 2, (r + 3) // 2, 1 << 751, (1 << 752) + 12345]
+    pts[12] = None
+    pts[14] = pts[13]; scal[14] = scal[13]
+    pts[16] = C.neg(pts[15]); scal[16] = scal[15]
+    b, inf = S.bases_array(C, pts)
+    s = S.scalar_array(scal)
+    exp = S.oracle_msm(curve, b, inf, s, 16)
+    exp_short = S.oracle_msm(curve, b, inf, s[:n // 3], 16)
+    rb = gpu.ResidentBases(curve, b, inf)
+    ds = gpu.DeviceBuffer(s.nbytes).upload(s)
+    try:
+        for c, max_rows in ((13, 1), (13, 2), (13, 5), (16, 7), (17, 3), (9, 1000), (0, 4)):
+            used = rb.precompute(c, max_rows)
+            windows = 752 // used + 1
+            sets = 1 if max_rows >= windows else -(-windows // max_rows)
+            assert rb.table_rows() == -(-windows // sets), (c, max_rows)
+            assert affine_eq(gpu, curve, rb.msm(s), exp), (curve, c, max_rows)
+            assert gpu.msm_last_timing()["window_bits"] == used
+            assert affine_eq(gpu, curve, rb.msm(s[:n // 3]), exp_short), (curve, c, max_rows, "short")
+            outs = gpu.msm_batch_dev([(rb, ds, n), (rb, ds, n // 3), (rb, ds, n)])
+            assert affine_eq(gpu, curve, outs[0], exp) and affine_eq(gpu, curve, outs[1], exp_short) and affine_eq(gpu, curve, outs[2], exp)
+    finally:
+        ds.free()
+        rb.free()
+
+
 def test_msm_precomputed_skewed_and_large(gpu):
     """witness-like scalars (long buckets -> chunk path) on the merged bucket set, and a 2^16-pair run
     against the oracle (BASELINE config 1 size) with the automatic table window"""
