@@ -565,7 +565,13 @@ int gh_msm_cached(gh_curve_t curve, const uint64_t* bases, const uint8_t* infini
     hit->sightings++;
     BasesBase* key = hit->key;
     if (kc.table_after > 0 && hit->sightings == (uint32_t)kc.table_after && !key->d_table && n >= 4096) {
-        const int prc = ops->precompute(key, 0, 0);   // optional: NOMEM / UNSUPPORTED leave the key on the per-window path
+        // a quarter of the cache's budget per table, so that the four G1 queries of a proving key stay resident together: the
+        // full table where it fits into that (2^20 bases: 7.8 of 16 GB), a partial one otherwise (2^24 bases: 4 rows, 14 GB)
+        const size_t row_bytes = key_bytes(key);                      // no table yet: the bases themselves = one row
+        size_t max_rows = row_bytes ? (kc.max_bytes / 4) / row_bytes : 0;
+        if (max_rows > 4096) max_rows = 4096;
+        const int prc = max_rows >= 2 ? ops->precompute(key, 0, (int)max_rows)   // optional: NOMEM / UNSUPPORTED leave the key on the per-window path
+                                      : GH_E_NOMEM;
         if (prc == GH_OK) kc.st.tables_built++;
         else (void)hipGetLastError();
         hit->bytes = key_bytes(key);
