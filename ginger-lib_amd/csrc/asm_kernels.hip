@@ -1,0 +1,83 @@
+// asm_kernels.hip -- loader and launcher of the hand-allocated gfx950 assembly kernels (ginger-lib_amd/asmgen/*.py).
+//
+// The kernels are generated, assembled and linked into ONE code object at build time (asmgen/build.py ->
+// build/gh_asm.hsaco) and embedded into this library as bytes (build/asm_blob.S, .incbin); here the code object is
+// handed to hipModuleLoadData once per process and its kernels are launched with hipModuleLaunchKernel on the caller's
+// stream.  They replace hipcc-compiled kernels one for one (same inputs, same outputs: csrc/msm_kernels.h names the
+// counterpart next to each), so every parity test runs through them; GH_ACC_ASM=0 selects the hipcc kernels for A/B runs.
+#include "asm_kernels.h"
+#include <stdlib.h>
+#include <string.h>
+
+extern "C" const unsigned char gh_asm_hsaco[];
+extern "C" const unsigned char gh_asm_hsaco_end[];
+
+namespace gh_asm {
+
+using gh_rt::g;
+using gh_rt::g_err;
+
+namespace {
+struct State {
+    bool tried = false;
+    hipModule_t mod = nullptr;
+    hipFunction_t acc_g1[2] = {nullptr, nullptr};   // [0]: p4 (MNT4-753 G1), [1]: p6 (MNT6-753 G1)
+};
+State s;
+
+int load_locked() {
+    if (s.tried) return s.mod ? GH_OK : GH_E_HIP;
+    s.tried = true;
+    const size_t bytes = (size_t)(gh_asm_hsaco_end - gh_asm_hsaco);
+    if (bytes < 64 || memcmp(gh_asm_hsaco, "\177ELF", 4) != 0) {
+        g_err = "assembly code object missing from the library (build/gh_asm.hsaco was not embedded)";
+        return GH_E_HIP;
+    }
+    hipModule_t m = nullptr;
+    hipError_t e = hipModuleLoadData(&m, gh_asm_hsaco);
+    if (e != hipSuccess) {
+        g_err = std::string("hipModuleLoadData(assembly kernels) failed: ") + hipGetErrorString(e);
+        return GH_E_HIP;
+    }
+    static const char* names[2] = {"gh_asm_acc_g1_p4", "gh_asm_acc_g1_p6"};
+    for (int i = 0; i < 2; i++) {
+        e = hipModuleGetFunction(&s.acc_g1[i], m, names[i]);
+        if (e != hipSuccess) {
+            g_err = std::string("hipModuleGetFunction(") + names[i] + ") failed: " + hipGetErrorString(e);
+            hipModuleUnload(m);
+            return GH_E_HIP;
+        }
+    }
+    s.mod = m;
+    g.at_shutdown.push_back([] {
+        if (s.mod) hipModuleUnload(s.mod);
+        s = State();
+    });
+    return GH_OK;
+}
+}  // namespace
+
+bool enabled() {
+    static const bool on = !(getenv("GH_ACC_ASM") && atoi(getenv("GH_ACC_ASM")) == 0);
+    return on;
+}
+
+int acc_g1_launch(int prime, const void* bases, const uint32_t* sorted, const AccTask* tasks, const void* salts,
+                  uint32_t n_tasks, hipStream_t st) {
+    if (n_tasks == 0) return GH_OK;
+    if (int rc = load_locked()) return rc;
+    struct {
+        const void* bases;
+        const void* sorted;
+        const void* tasks;
+        const void* salts;
+        uint32_t n_tasks;
+        uint32_t pad;
+    } args = {bases, sorted, tasks, salts, n_tasks, 0};
+    size_t size = sizeof args;
+    void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+    HIPCHK(hipModuleLaunchKernel(s.acc_g1[prime == 6 ? 1 : 0], (n_tasks + 255) / 256, 1, 1, 256, 1, 1, 0, st, nullptr, extra));
+    return GH_OK;
+}
+
+}  // namespace gh_asm

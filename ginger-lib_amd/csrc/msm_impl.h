@@ -8,6 +8,7 @@
 #include <vector>
 #include "runtime.h"
 #include "msm_kernels.h"
+#include "asm_kernels.h"
 #include "host_math.h"
 
 #ifndef GH_F3S_TRIPLE
@@ -648,7 +649,18 @@ struct MsmJob {
             static const bool acc_xyzz = !(getenv("GH_ACC_XYZZ") && atoi(getenv("GH_ACC_XYZZ")) == 0);
             bool done_xyzz = false;
             if constexpr (C::F::DEG == 1) {
-                if (acc_xyzz && acc_waves >= 2) {
+                if (acc_xyzz && acc_waves >= 2 && gh_asm::enabled()) {
+                    // the assembly kernel (asmgen/g1_xyzz.py): the same updates on a fixed register plan, 0 B of scratch
+                    gh_asm::AccTask* tk = nullptr;
+                    snprintf(nm, sizeof nm, "acc_tasks#%d", slot);
+                    if ((rc = pool_get(nm, tasks * sizeof(gh_asm::AccTask), (void**)&tk))) return rc;
+                    hipLaunchKernelGGL((msm_acc_tasks_kernel<C>), dim3((unsigned)((tasks + 255) / 256)), dim3(256), 0, st,
+                                       (const uint32_t*)starts, (const uint32_t*)counts, (const uint32_t*)order, (uint32_t)total, buckets,
+                                       (const uint32_t*)chunk_start, n_heavy, n_chunks, heavy_chunk, partials, (AccTaskRec*)tk);
+                    if ((rc = gh_asm::acc_g1_launch(std::is_same<typename C::PF, P6>::value ? 6 : 4, src_points, (const uint32_t*)sorted, tk,
+                                                    salts, (uint32_t)tasks, st))) return rc;
+                    done_xyzz = true;
+                } else if (acc_xyzz && acc_waves >= 2) {
                     hipLaunchKernelGGL((msm_accumulate_xyzz_kernel<C>), dim3((unsigned)((tasks + 255) / 256)), dim3(256), 0, st,
                                        (const Aff<C>*)src_points, (const uint32_t*)sorted, (const uint32_t*)starts,
                                        (const uint32_t*)counts, (const uint32_t*)order, (uint32_t)total, (const Aff<C>*)salts, buckets,
@@ -978,9 +990,17 @@ int accumulate_lists(const void* points, const uint32_t* sorted, const uint32_t*
     Aff<C>* salts = nullptr;
     if (int rc = device_salts<C>(&salts)) return rc;
     if constexpr (C::F::DEG == 1) {
+      if (gh_asm::enabled()) {
+        gh_asm::AccTask* tk = nullptr;
+        if (int rc = pool_get("acc_tasks#lists", (size_t)total * sizeof(gh_asm::AccTask), (void**)&tk)) return rc;
+        hipLaunchKernelGGL((msm_acc_tasks_kernel<C>), dim3((unsigned)(((size_t)total + 255) / 256)), dim3(256), 0, st, starts, counts, order,
+                           total, (Proj<C>*)out_proj, (const uint32_t*)nullptr, 0u, 0u, 0u, (Proj<C>*)nullptr, (AccTaskRec*)tk);
+        if (int rc = gh_asm::acc_g1_launch(std::is_same<typename C::PF, P6>::value ? 6 : 4, points, sorted, tk, salts, total, st)) return rc;
+      } else {
         hipLaunchKernelGGL((msm_accumulate_xyzz_kernel<C>), dim3((unsigned)(((size_t)total + 255) / 256)), dim3(256), 0, st,
                            (const Aff<C>*)points, sorted, starts, counts, order, total, (const Aff<C>*)salts, (Proj<C>*)out_proj,
                            (const uint32_t*)nullptr, 0u, 0u, 0u, (Proj<C>*)nullptr, 0u, 0u);
+      }
     } else {
         typedef typename std::conditional<std::is_same<C, Mnt4G2>::value, F2S<P4, 13, GH_F2S_DUAL != 0>, F3S<P6, 11, GH_F3S_TRIPLE>>::type FS;
         constexpr int LANES = FS::LANES;

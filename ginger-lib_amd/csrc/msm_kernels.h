@@ -730,6 +730,37 @@ msm_accumulate_kernel(const Aff<C>* __restrict__ bases, const uint32_t* __restri
     st_proj<C>(dst, acc);
 }
 
+// ---------------------------------------------------------------- 4-asm. task table of the assembly accumulation kernel
+// The task decode of msm_accumulate_kernel / msm_accumulate_xyzz_kernel (chunks of the heavy buckets first, then every other
+// bucket by descending size) as a table, so that the assembly kernel (asmgen/g1_xyzz.py) starts from (beg, cnt, dst).
+struct AccTaskRec {
+    uint32_t beg, cnt;
+    uint64_t dst;
+};
+template <class C>
+__global__ void __launch_bounds__(256)
+msm_acc_tasks_kernel(const uint32_t* __restrict__ starts, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ order,
+                     uint32_t total, Proj<C>* __restrict__ buckets, const uint32_t* __restrict__ chunk_start, uint32_t n_heavy,
+                     uint32_t n_chunks, uint32_t chunk, Proj<C>* __restrict__ partials, AccTaskRec* __restrict__ out) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_chunks + (total - n_heavy)) return;
+    AccTaskRec r;
+    if (t >= n_chunks) {
+        const uint32_t g = order[n_heavy + (t - n_chunks)];
+        r.beg = starts[g]; r.cnt = counts[g];
+        r.dst = (uint64_t)(uintptr_t)(buckets + g);
+    } else {
+        uint32_t lo = 0, hi = n_heavy;   // largest h with chunk_start[h] <= t
+        while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (chunk_start[mid] <= t) lo = mid; else hi = mid; }
+        const uint32_t g = order[lo], j = t - chunk_start[lo];
+        r.beg = starts[g] + j * chunk;
+        uint32_t cnt = counts[g] - j * chunk;
+        r.cnt = cnt > chunk ? chunk : cnt;
+        r.dst = (uint64_t)(uintptr_t)(partials + t);
+    }
+    out[t] = r;
+}
+
 // ---------------------------------------------------------------- 4a. G1 bucket accumulation on XYZZ accumulators
 // The same task list, the same list walk and the same salt detour as msm_accumulate_kernel, with the running sum in
 // extended Jacobian coordinates (ec29.h, Xyzz): madd-2008-s, 8 M + 2 S, and Y3 as one dual product on a single
