@@ -21,10 +21,15 @@ R = 1 << 754
 
 
 def programs():
-    return [
+    progs = [
         g1_xyzz.build("gh_asm_acc_g1_p4", P4, R % P4),
         g1_xyzz.build("gh_asm_acc_g1_p6", P6, R % P6),
     ]
+    if os.environ.get("GH_ASM_VARIANTS"):      # A/B variants of the gather for tools/asm_mb/acc_run.hip (not shipped)
+        progs += [g1_xyzz.build("gh_asm_acc_g1_p4_s1", P4, R % P4, split=1),
+                  g1_xyzz.build("gh_asm_acc_g1_p4_s2", P4, R % P4, split=2),
+                  g1_xyzz.build("gh_asm_acc_g1_p4_s1pf", P4, R % P4, split=1, prefetch=True)]
+    return progs
 
 
 def build(outdir):

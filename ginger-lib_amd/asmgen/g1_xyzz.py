@@ -52,6 +52,9 @@ V_T = [V(14), V(15), V(16), V(17), V(18), V(19)]
 V_BASES, V_SALTS = V(20, 2), V(22, 2)
 V_TMP = V(39)
 V_LDS2 = V(24)
+V_ENEXT = V(25)
+V_TOUCH = V(26)
+V_NADDR = V(28, 2)
 
 
 def slot(i):
@@ -61,7 +64,7 @@ def slot(i):
 E = [slot(i) for i in range(8)]
 
 
-def build(name, p, one_mont):
+def build(name, p, one_mont, prefetch=False, split=4):
     """p: the base prime; one_mont = 2^754 mod p (internal Montgomery one)."""
     g = Prog(name)
     g.lds_bytes = LDS_BYTES
@@ -162,6 +165,12 @@ def build(name, p, one_mont):
     g.s_cbranch_execz(L_DONE)
     # the entry of phases 0 / 2 (read by every active lane: the cursor stays inside the list while entries are left)
     g.global_load_dword(V_E, V_CUR, OFF)
+    if prefetch:                                                    # the entry after this one (the same again at the end of the list)
+        g.v_cmp_lt_u32(S_T1, 1, V_LEFT)
+        g.v_cndmask_b32(V_T[2], 0, 4, S_T1)
+        g.v_add_co_u32(V_NADDR.lo(), VCC, V_CUR.lo(), V_T[2])
+        g.v_addc_co_u32(V_NADDR.hi(), VCC, 0, V_CUR.hi(), VCC)
+        g.global_load_dword(V_ENEXT, V_NADDR, OFF)
     g.v_and_b32(V_T[1], 1, V_PHASE)
     g.v_cmp_ne_u32(S_T0, 0, V_T[1])                                 # S_T0 = lanes in a salt phase (1, 3)
     g.v_mad_u64_u32(V(16, 2), chA.sdum, V_SALT, S_208, V_SALTS)
@@ -170,8 +179,19 @@ def build(name, p, one_mont):
     g.v_mad_u64_u32(V_ADDR, chA.sdum, V_T[0], S_208, V_BASES)
     g.v_cndmask_b32(V_ADDR.lo(), V_ADDR.lo(), V(16), S_T0)
     g.v_cndmask_b32(V_ADDR.hi(), V_ADDR.hi(), V(17), S_T0)
-    for j in range(AFF_BYTES // 16):                                # E2 = q.x, E3 = q.y (contiguous)
-        g.global_load_dwordx4(V(E[2].idx + 4 * j, 4), V_ADDR, OFF, offset=16 * j)
+    # E2 = q.x, E3 = q.y (contiguous).  Every lane reads its own row: one wave-wide load touches 64 pages, more than the L1 TLB
+    # holds, so each of a row's 13 loads would miss all of its translations again (profiles/r02_affine_rounds_counters.txt:
+    # TCP_UTCL1_TRANSLATION_MISS 13 per row).  A part of the wave at a time, all 13 loads of its rows back to back.
+    if split > 1:
+        g.s_mov_b64(S_SAVE, EXEC)
+    for q in range(split):
+        if split > 1:
+            g.s_bfm_b64(S_T1, 64 // split, (64 // split) * q)
+            g.s_and_b64(EXEC, S_SAVE, S_T1)
+        for j in range(AFF_BYTES // 16):
+            g.global_load_dwordx4(V(E[2].idx + 4 * j, 4), V_ADDR, OFF, offset=16 * j)
+    if split > 1:
+        g.s_mov_b64(EXEC, S_SAVE)
     # negate q.y on lanes where (entry sign, or phase == 3 for the salt) != sigma
     g.v_lshrrev_b32(V_T[0], 31, V_E)
     g.v_lshrrev_b32(V_T[1], 1, V_PHASE)
@@ -179,6 +199,15 @@ def build(name, p, one_mont):
     g.v_xor_b32(V_T[0], V_T[0], V_SNEG)
     g.v_cmp_ne_u32(S_NEGSEL, 0, V_T[0])
     g.s_waitcnt(vmcnt=0)
+    if prefetch:
+        # Touch the NEXT entry's row (its four 64-byte lines) now, a whole update ahead: the gathers are one row per lane out of a
+        # multi-GB table, i.e. 64 address translations per wave instruction; with the lines and translations warm the
+        # gather at the top of the next iteration returns from L2 (tools/asm_mb/acc_run: 74.5 K -> 68.7 K cycles per update
+        # is the cost of the cold gather).  The loaded words are never read.
+        g.v_and_b32(V_T[2], 0x7FFFFFFF, V_ENEXT)
+        g.v_mad_u64_u32(V_NADDR, chA.sdum, V_T[2], S_208, V_BASES)
+        for j in range(4):
+            g.global_load_dword(V_TOUCH, V_NADDR, OFF, offset=min(64 * j, AFF_BYTES - 4))
     run(f.neg_sel(chA, E[3], V_TMP, S_NEGSEL))
     run(f.is_zero_mask(chA, E[0], S_ZERO))
     g.s_cmp_lg_u64(S_ZERO, 0)

@@ -505,6 +505,12 @@ HANDLERS["s_andn2_b64"] = _s64bin(lambda a, b: a & ~b)
 HANDLERS["s_orn2_b64"] = _s64bin(lambda a, b: a | ~b)
 
 
+@op("s_bfm_b64")
+def _s_bfm64(w, i):
+    d, a, b = i.args
+    w.wr_smask(d, (((1 << (w.rs(a) & 63)) - 1) << (w.rs(b) & 63)) & 0xFFFFFFFFFFFFFFFF)
+
+
 @op("s_not_b64")
 def _s_not64(w, i):
     d, a = i.args

@@ -1,0 +1,316 @@
+"""Micro-benchmarks of the assembly building blocks (ginger-lib_amd/asmgen): every kernel repeats ONE block `iters` times on
+the register plan of the G1 accumulation kernel, at two waves per SIMD (LDS pinned to 79 872 B per block).  The driver
+(tools/asm_mb/run.hip) loads the code object and times each kernel:  python tools/asm_mb/gen.py OUTDIR
+"""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(ROOT, "ginger-lib_amd"))
+from asmgen.isa import Prog, V, S, VCC, EXEC, OFF, module_text          # noqa: E402
+from asmgen.field import FieldGen, Chain, interleave, run, NL, LM      # noqa: E402
+from asmgen import g1_xyzz                                             # noqa: E402
+from asmgen.build import P4, LLVM                                      # noqa: E402
+
+E = g1_xyzz.E
+BLOCKS = {}
+
+
+def block(name):
+    def deco(fn):
+        BLOCKS[name] = fn
+        return fn
+    return deco
+
+
+@block("mul_pair")
+def _(g, f, A, B):
+    interleave(f.mul(A, E[2], E[0], E[4], E[2]), f.mul(B, E[3], E[1], E[5], E[3]))
+    return 2
+
+
+@block("mul_pair_noreduce")
+def _(g, f, A, B):
+    interleave(f.mul(A, E[2], E[0], E[4], E[2], reduce=False), f.mul(B, E[3], E[1], E[5], E[3], reduce=False))
+    return 2
+
+
+@block("mul_single")
+def _(g, f, A, B):
+    run(f.mul(A, E[2], E[0], E[4], E[2]))
+    return 1
+
+
+@block("mul_seq2")
+def _(g, f, A, B):
+    run(f.mul(A, E[2], E[0], E[4], E[2]))
+    run(f.mul(B, E[3], E[1], E[5], E[3]))
+    return 2
+
+
+@block("sqr_pair")
+def _(g, f, A, B):
+    interleave(f.sqr(A, E[4], E[2], E[6]), f.sqr(B, E[5], E[3], E[7]))
+    return 2
+
+
+@block("dual")
+def _(g, f, A, B):
+    run(f.dual(A, B, E[5], E[2], E[6], E[4], E[7], E[6]))
+    return 1
+
+
+@block("sub_pair")
+def _(g, f, A, B):
+    interleave(f.sub(A, E[4], E[2], E[4]), f.sub(B, E[5], E[3], E[5]))
+    return 2
+
+
+@block("sub_single")
+def _(g, f, A, B):
+    run(f.sub(A, E[4], E[2], E[4]))
+    return 1
+
+
+@block("condsub_pair")
+def _(g, f, A, B):
+    interleave(f.cond_sub(A, E[4], E[2], E[4]), f.cond_sub(B, E[5], E[3], E[5]))
+    return 2
+
+
+@block("neg_sel")
+def _(g, f, A, B):
+    run(f.neg_sel(A, E[3], V(39), S(78, 2)))
+    return 1
+
+
+@block("mads_only_pair")
+def _(g, f, A, B):
+    # 2 x 1352 mads alternating on two accumulators, nothing else
+    for k in range(1352):
+        g.v_mad_u64_u32(A.acc, A.sdum, E[2].sub(k % 26), E[0].sub((k * 7) % 26), A.acc)
+        g.v_mad_u64_u32(B.acc, B.sdum, E[3].sub(k % 26), E[1].sub((k * 7) % 26), B.acc)
+    return 2
+
+
+@block("mads_only_pair_sgpr")
+def _(g, f, A, B):
+    for k in range(1352):
+        g.v_mad_u64_u32(A.acc, A.sdum, E[2].sub(k % 26), f.sP(k % 26), A.acc)
+        g.v_mad_u64_u32(B.acc, B.sdum, E[3].sub(k % 26), f.sP((k + 3) % 26), B.acc)
+    return 2
+
+
+@block("mads_only_pair_vcc")
+def _(g, f, A, B):
+    for k in range(1352):
+        g.v_mad_u64_u32(A.acc, VCC, E[2].sub(k % 26), E[0].sub((k * 7) % 26), A.acc)
+        g.v_mad_u64_u32(B.acc, VCC, E[3].sub(k % 26), E[1].sub((k * 7) % 26), B.acc)
+    return 2
+
+
+@block("mads_only_single")
+def _(g, f, A, B):
+    for k in range(2704):
+        g.v_mad_u64_u32(A.acc, A.sdum, E[2].sub(k % 26), E[0].sub((k * 7) % 26), A.acc)
+    return 2
+
+
+@block("mads_only_quad")
+def _(g, f, A, B):
+    # four accumulators
+    accs = [A.acc, B.acc, V(30, 2), V(32, 2)]
+    for k in range(676):
+        for j, a in enumerate(accs):
+            g.v_mad_u64_u32(a, A.sdum, E[2 + (j & 1)].sub(k % 26), E[j & 1].sub((k * 7) % 26), a)
+    return 2
+
+
+@block("close_low_pair")
+def _(g, f, A, B):
+    # 26 column closings (mul_lo, and, mad, alignbit, lshr) per chain, interleaved; x 10 to make the block long enough
+    for _ in range(10):
+        for k in range(NL):
+            interleave(f._close_low(A, E[4], k), f._close_low(B, E[5], k))
+    return 20
+
+
+@block("park_roundtrip")
+def _(g, f, A, B):
+    for _ in range(10):
+        for w in range(NL):
+            g.ds_write_b32(V(1), E[4].sub(w), offset=w * 1024)
+        for w in range(NL):
+            g.ds_read_b32(E[5].sub(w), V(1), offset=w * 1024)
+        g.s_waitcnt(lgkmcnt=0)
+    return 10
+
+
+@block("sqr_seq2")
+def _(g, f, A, B):
+    run(f.sqr(A, E[4], E[2], E[6]))
+    run(f.sqr(B, E[5], E[3], E[7]))
+    return 2
+
+
+@block("mul_seq2_sameA")
+def _(g, f, A, B):
+    run(f.mul(A, E[2], E[0], E[4], E[2]))
+    run(f.mul(A, E[3], E[1], E[5], E[3]))
+    return 2
+
+
+@block("mul_pair_samedum")
+def _(g, f, A, B):
+    B2 = Chain(B.acc, B.t0, B.t1, A.sdum, B.scar)
+    interleave(f.mul(A, E[2], E[0], E[4], E[2]), f.mul(B2, E[3], E[1], E[5], E[3]))
+    return 2
+
+
+@block("mul_pair_oddbank")
+def _(g, f, A, B):
+    # chain B's three slots start at registers = 1 mod 4 (chain A's at 0 mod 4)
+    a, b, m = V(117, 26), V(65, 26), V(169, 26)
+    interleave(f.mul(A, E[2], E[0], E[4], E[2], reduce=False), f.mul(B, a, b, m, a, reduce=False))
+    return 2
+
+
+@block("mul_pair_sharedb")
+def _(g, f, A, B):
+    # both products share the operand b (as PPP || ZZ3 do)
+    interleave(f.mul(A, E[2], E[0], E[4], E[2], reduce=False), f.mul(B, E[3], E[0], E[5], E[3], reduce=False))
+    return 2
+
+
+@block("mul_pair_percolumn")
+def _(g, f, A, B):
+    # coarser interleave: chain A does column k, then chain B does column k
+    ga = f.mont_columns(A, f.mul_terms(E[2], E[0]), E[4])
+    gb = f.mont_columns(B, f.mul_terms(E[3], E[1]), E[5])
+    def ncol(k):
+        lo = max(0, k - NL + 1); hi = min(k, NL - 1)
+        n = hi - lo + 1
+        n += (k if k < NL else 2 * NL - 1 - k)
+        n += 5 if k < NL else (1 if k == 2 * NL - 1 else 3)
+        return n
+    for k in range(2 * NL):
+        for gen in (ga, gb):
+            for _ in range(ncol(k)):
+                next(gen)
+    for gen in (ga, gb):
+        for _ in gen:
+            raise RuntimeError("column count mismatch")
+    return 2
+
+
+@block("mul_seq2_noreduce")
+def _(g, f, A, B):
+    run(f.mul(A, E[2], E[0], E[4], E[2], reduce=False))
+    run(f.mul(B, E[3], E[1], E[5], E[3], reduce=False))
+    return 2
+
+
+def _phase_block(pa, pb, pm, beta, kind="mul"):
+    # slots with base register = pa / pb / pm (mod 4), accumulator pair at bank beta
+    bases = {0: [40, 68, 96], 2: [126, 154, 182], 1: [41 + 170, 0, 0], 3: [0, 0, 0]}
+    def blk(g, f, A, B):
+        used = {0: 0, 2: 0}
+        def take(ph):
+            r = V(bases[ph][used[ph]], 26); used[ph] += 1
+            return r
+        a, b, m = take(pa), take(pb), take(pm)
+        ch = Chain(V(248 + beta, 2), V(252), V(253), S(14, 2), S(16, 2))
+        if kind == "mul":
+            run(f.mul(ch, a, b, m, a, reduce=False))
+        else:
+            for i in range(NL):
+                g.v_lshlrev_b32(b.sub(i), 1, a.sub(i))
+            run(f.mont_columns(ch, f.sqr_terms(a, b), m))
+        return 1
+    return blk
+
+
+for _pa in (0, 2):
+    for _pb in (0, 2):
+        for _pm in (0, 2):
+            for _beta in (0, 2):
+                BLOCKS["ph_mul_a%d_b%d_m%d_acc%d" % (_pa, _pb, _pm, _beta)] = _phase_block(_pa, _pb, _pm, _beta)
+for _pa in (0, 2):
+    for _pm in (0, 2):
+        for _beta in (0, 2):
+            BLOCKS["ph_sqr_a%d_a2%d_m%d_acc%d" % (_pa, _pa ^ 2, _pm, _beta)] = _phase_block(_pa, _pa ^ 2, _pm, _beta, "sqr")
+            BLOCKS["ph_sqr_a%d_a2%d_m%d_acc%d" % (_pa, _pa, _pm, _beta)] = _phase_block(_pa, _pa, _pm, _beta, "sqr")
+
+
+def _rep_block(n):
+    def blk(g, f, A, B):
+        for _ in range(n):
+            interleave(f.mul(A, E[2], E[0], E[4], E[2]), f.mul(B, E[3], E[1], E[5], E[3]))
+        return 2 * n
+    return blk
+
+
+for _n in (1, 2, 3, 4, 5, 6, 8):
+    BLOCKS["codesize_mulpair_x%d" % _n] = _rep_block(_n)
+
+
+def kernel(name, fn):
+    g = Prog("mb_" + name)
+    g.lds_bytes = g1_xyzz.LDS_BYTES
+    g.add_arg(4, "val")
+    g.add_arg(4, "val")
+    f = FieldGen(g, P4, g1_xyzz.S_P, g1_xyzz.S_NP, g1_xyzz.S_INV, g1_xyzz.S_LM)
+    A = Chain(V(248, 2), V(252), V(253), S(14, 2), S(16, 2))
+    B = Chain(V(250, 2), V(254), V(255), S(18, 2), S(22, 2))
+    g.s_load_dword(S(3), S(0, 2), 0)
+    f.load_constants()
+    g.v_lshlrev_b32(V(1), 2, V(0))
+    g.s_mov_b32(S(78), 0x0F0F3355); g.s_mov_b32(S(79), 0xAAAA00FF)
+    # operands: limbs derived from the lane id, below 2^29, top limb small so that values stay below p
+    for i in range(8):
+        for w in range(NL):
+            g.v_mov_b32(V(34), 0x1234567 + 977 * w + i)
+            g.v_mul_u32_u24(V(35), 0x9E37 + 131 * i + w, V(0))
+            g.v_add_u32(E[i].sub(w), V(34), V(35))
+            g.v_and_b32(E[i].sub(w), (LM >> 3) if w == NL - 1 else LM, E[i].sub(w))
+    g.v_mov_b32(A.acc.lo(), 0); g.v_mov_b32(A.acc.hi(), 0); g.v_mov_b32(B.acc.lo(), 0); g.v_mov_b32(B.acc.hi(), 0)
+    g.v_mov_b32(V(30), 0); g.v_mov_b32(V(31), 0); g.v_mov_b32(V(32), 0); g.v_mov_b32(V(33), 0)
+    g.s_waitcnt(lgkmcnt=0)
+    L = g.uniq("loop")
+    g.label(L)
+    n0 = g.count()
+    units = fn(g, f, A, B)
+    g.body_instr = g.count() - n0
+    g.s_sub_u32(S(3), S(3), 1)
+    g.s_cmp_lg_u32(S(3), 0)
+    Lx = g.uniq("exit")
+    g.s_cbranch_scc0(Lx)
+    g.long_branch(L, S(94, 2))
+    g.label(Lx)
+    g.s_endpgm()
+    return g, units
+
+
+def main(outdir):
+    os.makedirs(outdir, exist_ok=True)
+    progs, meta = [], []
+    only = os.environ.get('MB_ONLY')
+    for name, fn in BLOCKS.items():
+        if only and not any(name == o or (o.endswith('*') and name.startswith(o[:-1])) for o in only.split(',')):
+            continue
+        g, units = kernel(name, fn)
+        progs.append(g)
+        meta.append("%s %d %d" % (g.name, units, g.body_instr))
+    text, _ = module_text(progs)
+    s = os.path.join(outdir, "asm_mb.s")
+    open(s, "w").write(text)
+    subprocess.run([os.path.join(LLVM, "clang"), "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", s,
+                    "-o", os.path.join(outdir, "asm_mb.o")], check=True)
+    subprocess.run([os.path.join(LLVM, "ld.lld"), "-shared", os.path.join(outdir, "asm_mb.o"), "-o", os.path.join(outdir, "asm_mb.hsaco")], check=True)
+    open(os.path.join(outdir, "asm_mb.txt"), "w").write("\n".join(meta) + "\n")
+    print("\n".join(meta))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "build", "asm_mb"))
