@@ -32,6 +32,7 @@ ABI_SYMBOLS = [
     "gh_msm", "gh_bases_upload", "gh_bases_upload_wire", "gh_bases_generate_chain", "gh_bases_download", "gh_bases_free", "gh_bases_len", "gh_bases_precompute", "gh_bases_precomputed_window", "gh_bases_precompute_rows", "gh_bases_table_rows",
     "gh_msm_resident", "gh_msm_resident_dev", "gh_msm_resident_dev_batch",
     "gh_msm_cached", "gh_key_cache_config", "gh_key_cache_clear", "gh_key_cache_stats", "gh_bases_content_hash",
+    "gh_bases_key_id", "gh_test_hooks",
     "gh_msm_set_window", "gh_msm_set_affine", "gh_msm_get_window", "gh_msm_last_timing", "gh_msm_batch_timing",
     "gh_domain_supported", "gh_fft", "gh_fft_dev", "gh_vec_mul_dev", "gh_vec_sub_dev", "gh_vec_scale_dev",
     "gh_vec_mul", "gh_vec_scale", "gh_fft_last_kernel_ms", "gh_witness_map", "gh_witness_map_dev",
@@ -59,7 +60,7 @@ class MsmTiming(ctypes.Structure):
 
 
 class KeyCacheStats(ctypes.Structure):
-    _fields_ = [(k, ctypes.c_uint64) for k in ("entries", "bytes", "hits", "misses", "evictions", "tables_built")]
+    _fields_ = [(k, ctypes.c_uint64) for k in ("entries", "bytes", "hits", "misses", "evictions", "tables_built", "collisions")]
 
 
 _lib = None
@@ -100,6 +101,8 @@ def load_library():
     lib.gh_key_cache_stats.argtypes = [ctypes.POINTER(KeyCacheStats)]
     lib.gh_bases_content_hash.argtypes = [ci, vp, vp, sz, ctypes.POINTER(ctypes.c_uint64)]
     lib.gh_bases_content_hash.restype = ctypes.c_uint64
+    lib.gh_bases_key_id.argtypes = [ci, vp, vp, sz, ctypes.POINTER(ctypes.c_uint64)]
+    lib.gh_test_hooks.argtypes = [ci]
     lib.gh_msm_set_window.argtypes = [ci]
     lib.gh_msm_set_affine.argtypes = [ci]
     lib.gh_msm_get_window.argtypes = [ci, sz]
@@ -218,8 +221,9 @@ def msm_cached(curve, bases, scalars, infinity=None):
     return out
 
 
-def key_cache_config(max_bytes=64 << 30, table_after=2):
-    _check(load_library().gh_key_cache_config(int(max_bytes), int(table_after)))
+def key_cache_config(max_bytes=None, table_after=2):
+    """max_bytes None = GH_KEY_CACHE_AUTO: half of the device memory free at the next msm_cached call"""
+    _check(load_library().gh_key_cache_config((1 << 64) - 1 if max_bytes is None else int(max_bytes), int(table_after)))
 
 
 def key_cache_clear():
@@ -240,6 +244,21 @@ def bases_content_hash(curve, bases, infinity=None):
     hi = ctypes.c_uint64(0)
     lo = load_library().gh_bases_content_hash(CURVES[curve], _ptr(bases), _ptr(inf) if inf is not None else None, bases.size // (24 * deg), ctypes.byref(hi))
     return int(lo), int(hi.value)
+
+
+def bases_key_id(curve, bases, infinity=None):
+    """the four 64-bit lanes of a key's identity (gh_bases_key_id): [0:2] select the cache entry, [2:4] verify it; host-only"""
+    deg = CURVE_DEG[curve]
+    bases = _u64(bases, 24 * deg)
+    inf = None if infinity is None else np.ascontiguousarray(infinity, dtype=np.uint8)
+    out = (ctypes.c_uint64 * 4)()
+    _check(load_library().gh_bases_key_id(CURVES[curve], _ptr(bases), _ptr(inf) if inf is not None else None, bases.size // (24 * deg), out))
+    return tuple(int(x) for x in out)
+
+
+def set_test_hooks(flags):
+    """fault injection for the test-suite (gh_test_hooks): bit 0 = every key identity has constant selection lanes"""
+    _check(load_library().gh_test_hooks(int(flags)))
 
 
 class ResidentBases:

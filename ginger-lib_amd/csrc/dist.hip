@@ -149,7 +149,7 @@ void dist_teardown_locked() {
 
 extern "C" {
 
-int gh_dist_unique_id(void* out_id128) {
+int gh_dist_unique_id(void* out_id128) try {
     std::lock_guard<std::mutex> lk_api(api_mutex());
     std::lock_guard<std::mutex> lk(d_mu);
     if (!out_id128) { g_err = "null argument"; return GH_E_BAD_ARG; }
@@ -160,15 +160,15 @@ int gh_dist_unique_id(void* out_id128) {
     static_assert(sizeof(id) == GH_DIST_UNIQUE_ID_BYTES, "unique id size");
     memcpy(out_id128, &id, sizeof id);
     return GH_OK;
-}
+} catch (...) { return gh_rt::api_exception(); }
 
-int gh_dist_probe_rccl(void) {
+int gh_dist_probe_rccl(void) try {
     std::lock_guard<std::mutex> lk_api(api_mutex());
     std::lock_guard<std::mutex> lk(d_mu);
     return load_rccl();
-}
+} catch (...) { return gh_rt::api_exception(); }
 
-int gh_dist_init_rccl(const void* id128, int rank, int world) {
+int gh_dist_init_rccl(const void* id128, int rank, int world) try {
     int rc = gh_init(nullptr, 0);          // binds the device (no-op if the host already called gh_init); takes the API lock itself
     if (rc) return rc;
     std::lock_guard<std::mutex> lk_api(api_mutex());
@@ -198,9 +198,9 @@ int gh_dist_init_rccl(const void* id128, int rank, int world) {
     if (e != hipSuccess) { g_err = std::string("communicator buffers: ") + hipGetErrorString(e); return fail(e == hipErrorOutOfMemory ? GH_E_NOMEM : GH_E_HIP); }
     D.ready = true;
     return GH_OK;
-}
+} catch (...) { return gh_rt::api_exception(); }
 
-int gh_dist_init_custom(gh_allgather_fn fn, void* ctx, int rank, int world) {
+int gh_dist_init_custom(gh_allgather_fn fn, void* ctx, int rank, int world) try {
     std::lock_guard<std::mutex> lk_api(api_mutex());
     std::lock_guard<std::mutex> lk(d_mu);
     if (D.ready) { g_err = "a communicator already exists"; return GH_E_BAD_ARG; }
@@ -208,18 +208,18 @@ int gh_dist_init_custom(gh_allgather_fn fn, void* ctx, int rank, int world) {
     D.fn = fn; D.fn_ctx = ctx; D.rank = rank; D.world = world; D.comm = nullptr;
     D.ready = true;
     return GH_OK;
-}
+} catch (...) { return gh_rt::api_exception(); }
 
-int gh_dist_info(int* rank, int* world) {
+int gh_dist_info(int* rank, int* world) try {
     std::lock_guard<std::mutex> lk_api(api_mutex());
     std::lock_guard<std::mutex> lk(d_mu);
     if (!D.ready) { g_err = "no communicator (gh_dist_init_*)"; return GH_E_DIST; }
     if (rank) *rank = D.rank;
     if (world) *world = D.world;
     return GH_OK;
-}
+} catch (...) { return gh_rt::api_exception(); }
 
-int gh_dist_transport(int* rccl_ranks, int* rccl_version, char* path, size_t path_cap) {
+int gh_dist_transport(int* rccl_ranks, int* rccl_version, char* path, size_t path_cap) try {
     std::lock_guard<std::mutex> lk_api(api_mutex());
     std::lock_guard<std::mutex> lk(d_mu);
     int ranks = 0;
@@ -228,17 +228,17 @@ int gh_dist_transport(int* rccl_ranks, int* rccl_version, char* path, size_t pat
     if (rccl_version) *rccl_version = R.lib ? R.version : 0;
     if (path && path_cap) snprintf(path, path_cap, "%s%s", R.lib ? R.path.c_str() : "", R.lib && R.was_mapped ? " (already mapped by the host process)" : "");
     return GH_OK;
-}
+} catch (...) { return gh_rt::api_exception(); }
 
-int gh_partials_allgather_fold(gh_curve_t curve, const uint64_t* partial_xyz, uint64_t* out_xyz, double* exchange_us) {
+int gh_partials_allgather_fold(gh_curve_t curve, const uint64_t* partial_xyz, uint64_t* out_xyz, double* exchange_us) try {
     std::lock_guard<std::mutex> lk_api(api_mutex());
     std::lock_guard<std::mutex> lk(d_mu);
     if (!D.ready) { g_err = "no communicator (gh_dist_init_*)"; return GH_E_DIST; }
     if (!partial_xyz || !out_xyz || (int)curve < 0 || (int)curve > 3) { g_err = "bad argument"; return GH_E_BAD_ARG; }
     return exchange_fold(curve, partial_xyz, 1, out_xyz, exchange_us);
-}
+} catch (...) { return gh_rt::api_exception(); }
 
-int gh_partials_allgather_fold_batch(gh_curve_t curve, const uint64_t* partials_xyz, size_t count, uint64_t* outs_xyz, double* exchange_us) {
+int gh_partials_allgather_fold_batch(gh_curve_t curve, const uint64_t* partials_xyz, size_t count, uint64_t* outs_xyz, double* exchange_us) try {
     std::lock_guard<std::mutex> lk_api(api_mutex());
     std::lock_guard<std::mutex> lk(d_mu);
     if (!D.ready) { g_err = "no communicator (gh_dist_init_*)"; return GH_E_DIST; }
@@ -255,13 +255,13 @@ int gh_partials_allgather_fold_batch(gh_curve_t curve, const uint64_t* partials_
     }
     if (exchange_us) *exchange_us = total;
     return GH_OK;
-}
+} catch (...) { return gh_rt::api_exception(); }
 
-int gh_dist_shutdown(void) {
+int gh_dist_shutdown(void) try {
     std::lock_guard<std::mutex> lk_api(api_mutex());
     std::lock_guard<std::mutex> lk(d_mu);
     if (D.ready || D.comm) teardown();
     return GH_OK;
-}
+} catch (...) { return gh_rt::api_exception(); }
 
 }  // extern "C"

@@ -258,7 +258,7 @@ template <class C> int build_table(const uint64_t* g_xyz, size_t scalar_size, in
     if (e == hipSuccess) e = hipMemcpyAsync(d_g, gouter.data(), outerc * sizeof(Proj<C>), hipMemcpyHostToDevice, g.stream);
     if (e == hipSuccess) e = hipMemsetAsync(d_flag, 0, 4, g.stream);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL((fixed_table_kernel<C>), dim3((unsigned)((entries + 63) / 64)), dim3(64), 0, g.stream, (const Proj<C>*)d_g,
+        GH_LAUNCH((fixed_table_kernel<C>), dim3((unsigned)((entries + 63) / 64)), dim3(64), 0, g.stream, (const Proj<C>*)d_g,
                            window, outerc, last_in_window, (Aff<C>*)t->d_table, d_flag);
         e = hipGetLastError();
     }
@@ -286,7 +286,7 @@ template <> const MsmOps* fixed_ops<Mnt6G2>() { return msm_ops_mnt6753_g2(); }
 template <class C> int launch_fixed_sums(const FixedTable* t, const void* d_s, size_t n, void* d_o) {
     static const bool naive = getenv("GH_FIXED_NAIVE") && atoi(getenv("GH_FIXED_NAIVE")) != 0;
     if (naive || t->has_marks || n * (size_t)t->outerc >= ((size_t)1 << 31)) {
-        hipLaunchKernelGGL((fixed_msm_kernel<C>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, g.stream, (const Aff<C>*)t->d_table,
+        GH_LAUNCH((fixed_msm_kernel<C>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, g.stream, (const Aff<C>*)t->d_table,
                            t->window, t->outerc, t->scalar_size, (const uint32_t*)d_s, n, (Proj<C>*)d_o);
         HIPCHK(hipGetLastError());
         return GH_OK;
@@ -296,7 +296,7 @@ template <class C> int launch_fixed_sums(const FixedTable* t, const void* d_s, s
     if (!rc) rc = pool_get("fixed_meta", n * 12, (void**)&d_meta);
     if (rc) return rc;
     uint32_t *d_starts = d_meta, *d_counts = d_meta + n, *d_order = d_meta + 2 * n;
-    hipLaunchKernelGGL(fixed_digits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, g.stream, t->window, t->outerc, t->scalar_size,
+    GH_LAUNCH(fixed_digits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, g.stream, t->window, t->outerc, t->scalar_size,
                        (const uint32_t*)d_s, n, d_list, d_starts, d_counts, d_order);
     HIPCHK(hipGetLastError());
     return fixed_ops<C>()->acc_lists(t->d_table, d_list, d_starts, d_counts, d_order, (uint32_t)n, d_o, g.stream);
@@ -340,7 +340,7 @@ template <class C> int run_fixed_affine(const FixedTable* t, const uint64_t* sca
     HIPCHK(hipMemcpyAsync(d_s, scalars, n * 96, hipMemcpyHostToDevice, g.stream));
     if ((rc = launch_fixed_sums<C>(t, d_s, n, d_o))) return rc;
     const size_t threads = (n + NORM_RUN - 1) / NORM_RUN;
-    hipLaunchKernelGGL((fixed_normalize_kernel<C>), dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, g.stream, (const Proj<C>*)d_o, n, canonical,
+    GH_LAUNCH((fixed_normalize_kernel<C>), dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, g.stream, (const Proj<C>*)d_o, n, canonical,
                        (uint32_t*)d_xy, (uint8_t*)d_inf, (FT*)d_zp);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out_xy, d_xy, n * (size_t)(192 * F::DEG), hipMemcpyDeviceToHost, g.stream));
@@ -366,7 +366,7 @@ template <class C> int chain_bases(const uint64_t* p0_xy, const uint64_t* h_xy, 
         if (e == hipSuccess) e = hipMalloc((void**)&zs, n * sizeof(FT));
         if (e == hipSuccess) {
             const size_t threads = (n + CHAIN_RUN - 1) / CHAIN_RUN;
-            hipLaunchKernelGGL((chain_bases_kernel<C>), dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, g.stream, p0, h, n,
+            GH_LAUNCH((chain_bases_kernel<C>), dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, g.stream, p0, h, n,
                                (Aff<C>*)hb->d_points, zs);
             e = hipGetLastError();
         }
@@ -437,7 +437,7 @@ int gh_fixed_base_window(size_t num_scalars) {     // FixedBaseMSM::get_mul_wind
     return (int)ceil(log((double)(uint32_t)num_scalars));
 }
 
-int gh_fixed_base_table(gh_curve_t curve, const uint64_t* g_xyz, size_t scalar_size, int window, gh_fixed_table_t* out) {
+int gh_fixed_base_table(gh_curve_t curve, const uint64_t* g_xyz, size_t scalar_size, int window, gh_fixed_table_t* out) try {
     std::lock_guard<std::mutex> lk(api_mutex());
     if (!g_xyz || !out) { g_err = "null argument"; return GH_E_BAD_ARG; }
     if (window < 1 || window > 22 || scalar_size < 1 || scalar_size > 768) { g_err = "fixed-base window must be in [1, 22], scalar_size in [1, 768]"; return GH_E_BAD_ARG; }
@@ -449,9 +449,9 @@ int gh_fixed_base_table(gh_curve_t curve, const uint64_t* g_xyz, size_t scalar_s
     if (rc) { delete t; return rc; }
     *out = reinterpret_cast<gh_fixed_table_t>(t);
     return GH_OK;
-}
+} catch (...) { return gh_rt::api_exception(); }
 
-int gh_fixed_base_msm(gh_fixed_table_t table, const uint64_t* scalars, size_t n, uint64_t* out_xyz) {
+int gh_fixed_base_msm(gh_fixed_table_t table, const uint64_t* scalars, size_t n, uint64_t* out_xyz) try {
     std::lock_guard<std::mutex> lk(api_mutex());
     FixedTable* t = reinterpret_cast<FixedTable*>(table);
     if (!t || t->magic != 0x67684654u) { g_err = "bad fixed-base table handle"; return GH_E_BAD_HANDLE; }
@@ -459,9 +459,9 @@ int gh_fixed_base_msm(gh_fixed_table_t table, const uint64_t* scalars, size_t n,
     int rc = ensure_init();
     if (rc) return rc;
     return fixed_run(t, scalars, n, out_xyz);
-}
+} catch (...) { return gh_rt::api_exception(); }
 
-int gh_fixed_base_msm_affine(gh_fixed_table_t table, const uint64_t* scalars, size_t n, uint64_t* out_xy, uint8_t* out_inf, int canonical) {
+int gh_fixed_base_msm_affine(gh_fixed_table_t table, const uint64_t* scalars, size_t n, uint64_t* out_xy, uint8_t* out_inf, int canonical) try {
     std::lock_guard<std::mutex> lk(api_mutex());
     FixedTable* t = reinterpret_cast<FixedTable*>(table);
     if (!t || t->magic != 0x67684654u) { g_err = "bad fixed-base table handle"; return GH_E_BAD_HANDLE; }
@@ -469,9 +469,9 @@ int gh_fixed_base_msm_affine(gh_fixed_table_t table, const uint64_t* scalars, si
     int rc = ensure_init();
     if (rc) return rc;
     return fixed_run_affine(t, scalars, n, out_xy, out_inf, canonical);
-}
+} catch (...) { return gh_rt::api_exception(); }
 
-int gh_bases_generate_chain(gh_curve_t curve, const uint64_t* p0_xy, const uint64_t* step_xy, size_t n, gh_bases_t* out_handle) {
+int gh_bases_generate_chain(gh_curve_t curve, const uint64_t* p0_xy, const uint64_t* step_xy, size_t n, gh_bases_t* out_handle) try {
     std::lock_guard<std::mutex> lk(api_mutex());
     if (!p0_xy || !step_xy || !out_handle) { g_err = "null argument"; return GH_E_BAD_ARG; }
     if (n >= ((size_t)1 << 40)) { g_err = "chain too long"; return GH_E_BAD_ARG; }
@@ -488,9 +488,9 @@ int gh_bases_generate_chain(gh_curve_t curve, const uint64_t* p0_xy, const uint6
     if (rc) return rc;
     *out_handle = reinterpret_cast<gh_bases_t>(h);
     return GH_OK;
-}
+} catch (...) { return gh_rt::api_exception(); }
 
-int gh_bases_download(gh_bases_t handle, size_t first, size_t count, uint64_t* out_xy) {
+int gh_bases_download(gh_bases_t handle, size_t first, size_t count, uint64_t* out_xy) try {
     std::lock_guard<std::mutex> lk(api_mutex());
     BasesBase* h = reinterpret_cast<BasesBase*>(handle);
     if (!h || h->magic != 0x6768424au) { g_err = "bad bases handle"; return GH_E_BAD_HANDLE; }
@@ -505,9 +505,9 @@ int gh_bases_download(gh_bases_t handle, size_t first, size_t count, uint64_t* o
         case GH_MNT6753_G2: return download_bases<Mnt6G2>(h, first, count, out_xy);
     }
     return GH_E_BAD_ARG;
-}
+} catch (...) { return gh_rt::api_exception(); }
 
-int gh_fixed_base_free(gh_fixed_table_t table) {
+int gh_fixed_base_free(gh_fixed_table_t table) try {
     std::lock_guard<std::mutex> lk(api_mutex());
     FixedTable* t = reinterpret_cast<FixedTable*>(table);
     if (!t || t->magic != 0x67684654u) { g_err = "bad fixed-base table handle"; return GH_E_BAD_HANDLE; }
@@ -515,6 +515,6 @@ int gh_fixed_base_free(gh_fixed_table_t table) {
     t->magic = 0;
     delete t;
     return GH_OK;
-}
+} catch (...) { return gh_rt::api_exception(); }
 
 }  // extern "C"

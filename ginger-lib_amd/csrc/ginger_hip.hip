@@ -1,6 +1,11 @@
 // ginger_hip.hip -- the C ABI declared in include/ginger_hip.h plus the process-wide runtime
 // (device context, workspace pool, prefix scan).  Per-curve MSM code lives in msm_<curve>.hip,
 // the transforms in ntt.hip.  Build: __graft_entry__.py build() (hipcc --offload-arch=gfx950).
+#include <atomic>
+#include <condition_variable>
+#include <exception>
+#include <new>
+#include <random>
 #include <thread>
 #include <stdlib.h>
 #include <string.h>
@@ -61,6 +66,62 @@ int ensure_init() {
     return GH_OK;
 }
 
+int api_exception() noexcept {
+    int rc = GH_E_HIP;
+    const char* what = "unknown C++ exception";
+    char buf[384];
+    try {
+        throw;
+    } catch (const std::bad_alloc&) {
+        rc = GH_E_NOMEM;
+        what = "out of host memory (std::bad_alloc)";
+    } catch (const std::exception& e) {
+        snprintf(buf, sizeof buf, "C++ exception inside the library: %s", e.what());
+        what = buf;
+    } catch (...) {
+    }
+    try {
+        std::lock_guard<std::mutex> lk(g_mu);     // the entry point's own guard is gone: the stack has been unwound
+        g_err = what;
+    } catch (...) {
+    }
+    return rc;
+}
+
+int scratch_guard(const void* kernel, size_t threads) {
+    // frame size per kernel: one hipFuncGetAttributes per kernel and process
+    static std::map<const void*, size_t> frames;
+    size_t& reserved = g.scratch_reserved;           // what the runtime already holds for this context's queues (high-water mark)
+    auto it = frames.find(kernel);
+    if (it == frames.end()) {
+        hipFuncAttributes a;
+        memset(&a, 0, sizeof a);
+        size_t f = 0;
+        if (hipFuncGetAttributes(&a, kernel) == hipSuccess) f = a.localSizeBytes;
+        else (void)hipGetLastError();
+        it = frames.emplace(kernel, f).first;
+    }
+    const size_t frame = it->second;
+    if (frame < 1024) return GH_OK;                  // a few MB at most: never the problem
+    // the runtime sizes the reservation for the waves that can be resident, not for the grid
+    const size_t resident = (size_t)g.num_cus * 32 * 64;
+    const size_t lanes = threads < resident ? (threads + 63) / 64 * 64 : resident;
+    const size_t need = frame * lanes;
+    if (need <= reserved) return GH_OK;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return GH_OK; }
+    const size_t margin = (size_t)256 << 20;
+    if (free_b < need - reserved + margin) {
+        char b[256];
+        snprintf(b, sizeof b, "not enough device memory for the kernel's stack frames: %zu B per lane x %zu lanes = %zu MB of scratch, %zu MB free",
+                 frame, lanes, need >> 20, free_b >> 20);
+        g_err = b;
+        return GH_E_NOMEM;
+    }
+    reserved = need;
+    return GH_OK;
+}
+
 int pool_get(const char* name, size_t bytes, void** out) {
     DevBuf& b = g.pool[name];
     if (b.cap < bytes) {
@@ -98,9 +159,9 @@ int device_scan(const uint32_t* in, uint32_t* out, size_t n, const char* tmpname
     uint32_t* sums;
     int rc = pool_get(tmpname, (nblocks + 1) * 4, (void**)&sums);
     if (rc) return rc;
-    hipLaunchKernelGGL(scan_partials_kernel, dim3((unsigned)nblocks), dim3(SCAN_BLOCK), 0, stream, in, sums, n);
-    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, stream, sums, nblocks);
-    hipLaunchKernelGGL(scan_final_kernel, dim3((unsigned)nblocks), dim3(SCAN_BLOCK), 0, stream, in, sums, out, n);
+    GH_LAUNCH(scan_partials_kernel, dim3((unsigned)nblocks), dim3(SCAN_BLOCK), 0, stream, in, sums, n);
+    GH_LAUNCH(scan_block_sums_kernel, dim3(1), dim3(1024), 0, stream, sums, nblocks);
+    GH_LAUNCH(scan_final_kernel, dim3((unsigned)nblocks), dim3(SCAN_BLOCK), 0, stream, in, sums, out, n);
     HIPCHK(hipGetLastError());
     return GH_OK;
 }
@@ -142,7 +203,7 @@ using namespace gh_rt;
 // ==========================================================================================
 extern "C" {
 
-int gh_init(const int* devices, int n_devices) {
+int gh_init(const int* devices, int n_devices) try {
     std::lock_guard<std::mutex> lk(g_mu);
     if (g.ready) return GH_OK;
     if (devices && n_devices > 0) {
@@ -152,9 +213,9 @@ int gh_init(const int* devices, int n_devices) {
         g_device_req = devices[0];
     }
     return ensure_init();
-}
+} catch (...) { return gh_rt::api_exception(); }
 
-int gh_shutdown(void) {
+int gh_shutdown(void) try {
     std::lock_guard<std::mutex> lk(g_mu);
     dist_teardown_locked();              // a communicator must not outlive the streams and the device binding it was made on
     if (!g.ready) return GH_OK;
@@ -180,24 +241,25 @@ int gh_shutdown(void) {
     hipStreamDestroy(g.stream_acc);
     hipStreamDestroy(g.stream_red);
     hipStreamDestroy(g.stream);
+    g.scratch_reserved = 0;
     g.ready = false;
     return GH_OK;
-}
+} catch (...) { return gh_rt::api_exception(); }
 
-const char* gh_last_error(void) {
+const char* gh_last_error(void) try {
     static thread_local std::string tl;
     std::lock_guard<std::mutex> lk(g_mu);
     tl = g_err;
     return tl.c_str();
-}
-const char* gh_device_name(void) {
+} catch (...) { (void)gh_rt::api_exception(); return "C++ exception inside the library"; }
+const char* gh_device_name(void) try {
     std::lock_guard<std::mutex> lk(g_mu);
     if (ensure_init()) return "";
     return g_devname;
-}
+} catch (...) { (void)gh_rt::api_exception(); return "C++ exception inside the library"; }
 
 int gh_msm(gh_curve_t curve, const uint64_t* bases, const uint8_t* infinity, size_t n_bases, const uint64_t* scalars,
-           size_t n_scalars, uint64_t* out_xyz) {
+           size_t n_scalars, uint64_t* out_xyz) try {
     std::lock_guard<std::mutex> lk(g_mu);
     if (!out_xyz || (n_bases && !bases) || (n_scalars && !scalars)) { g_err = "null argument"; return GH_E_BAD_ARG; }
     const MsmOps* ops = ops_of(curve);
@@ -205,9 +267,9 @@ int gh_msm(gh_curve_t curve, const uint64_t* bases, const uint8_t* infinity, siz
     int rc = ensure_init();
     if (rc) return rc;
     return ops->host(bases, infinity, n_bases, scalars, n_scalars, out_xyz);
-}
+} catch (...) { return gh_rt::api_exception(); }
 
-int gh_bases_upload(gh_curve_t curve, const uint64_t* bases, const uint8_t* infinity, size_t n_bases, gh_bases_t* out_handle) {
+int gh_bases_upload(gh_curve_t curve, const uint64_t* bases, const uint8_t* infinity, size_t n_bases, gh_bases_t* out_handle) try {
     std::lock_guard<std::mutex> lk(g_mu);
     if (!out_handle || (n_bases && !bases)) { g_err = "null argument"; return GH_E_BAD_ARG; }
     const MsmOps* ops = ops_of(curve);
@@ -219,11 +281,11 @@ int gh_bases_upload(gh_curve_t curve, const uint64_t* bases, const uint8_t* infi
     if (rc) return rc;
     *out_handle = reinterpret_cast<gh_bases_t>(h);
     return GH_OK;
-}
+} catch (...) { return gh_rt::api_exception(); }
 
 // GroupAffine::write (short_weierstrass_projective.rs:185-192): x || y || infinity byte, every base-field
 // coefficient as 96 little-endian bytes of its CANONICAL integer (Fp768::write = into_repr().write, fp_768.rs:784-789).
-int gh_bases_upload_wire(gh_curve_t curve, const uint8_t* bytes, size_t n_points, gh_bases_t* out_handle) {
+int gh_bases_upload_wire(gh_curve_t curve, const uint8_t* bytes, size_t n_points, gh_bases_t* out_handle) try {
     std::lock_guard<std::mutex> lk(g_mu);
     if (!out_handle || (n_points && !bytes)) { g_err = "null argument"; return GH_E_BAD_ARG; }
     const MsmOps* ops = ops_of(curve);
@@ -253,9 +315,9 @@ int gh_bases_upload_wire(gh_curve_t curve, const uint8_t* bytes, size_t n_points
     if (rc) return rc;
     *out_handle = reinterpret_cast<gh_bases_t>(h);
     return GH_OK;
-}
+} catch (...) { return gh_rt::api_exception(); }
 
-int gh_bases_free(gh_bases_t handle) {
+int gh_bases_free(gh_bases_t handle) try {
     std::lock_guard<std::mutex> lk(g_mu);
     BasesBase* h = reinterpret_cast<BasesBase*>(handle);
     if (!h || h->magic != 0x6768424au) { g_err = "bad bases handle"; return GH_E_BAD_HANDLE; }
@@ -265,9 +327,9 @@ int gh_bases_free(gh_bases_t handle) {
     h->magic = 0;
     delete h;
     return GH_OK;
-}
+} catch (...) { return gh_rt::api_exception(); }
 
-int gh_bases_precompute_rows(gh_bases_t handle, int window_bits, int max_rows) {
+int gh_bases_precompute_rows(gh_bases_t handle, int window_bits, int max_rows) try {
     std::lock_guard<std::mutex> lk(g_mu);
     BasesBase* h = reinterpret_cast<BasesBase*>(handle);
     if (!h || h->magic != 0x6768424au) { g_err = "bad bases handle"; return GH_E_BAD_HANDLE; }
@@ -278,24 +340,24 @@ int gh_bases_precompute_rows(gh_bases_t handle, int window_bits, int max_rows) {
     int rc = ensure_init();
     if (rc) return rc;
     return ops->precompute(h, window_bits, max_rows);
-}
+} catch (...) { return gh_rt::api_exception(); }
 int gh_bases_precompute(gh_bases_t handle, int window_bits) { return gh_bases_precompute_rows(handle, window_bits, 0); }
-int gh_bases_table_rows(gh_bases_t handle) {
+int gh_bases_table_rows(gh_bases_t handle) try {
     BasesBase* h = reinterpret_cast<BasesBase*>(handle);
     return (h && h->magic == 0x6768424au && h->d_table) ? h->pre_W : 0;
-}
+} catch (...) { return gh_rt::api_exception(); }
 
-int gh_bases_precomputed_window(gh_bases_t handle) {
+int gh_bases_precomputed_window(gh_bases_t handle) try {
     BasesBase* h = reinterpret_cast<BasesBase*>(handle);
     return (h && h->magic == 0x6768424au && h->d_table) ? h->pre_c : 0;
-}
+} catch (...) { return gh_rt::api_exception(); }
 
-size_t gh_bases_len(gh_bases_t handle) {
+size_t gh_bases_len(gh_bases_t handle) try {
     BasesBase* h = reinterpret_cast<BasesBase*>(handle);
     return (h && h->magic == 0x6768424au) ? h->n : 0;
-}
+} catch (...) { (void)gh_rt::api_exception(); return 0; }
 
-int gh_msm_resident_dev(gh_bases_t handle, const void* d_scalars, size_t n_scalars, uint64_t* out_xyz) {
+int gh_msm_resident_dev(gh_bases_t handle, const void* d_scalars, size_t n_scalars, uint64_t* out_xyz) try {
     std::lock_guard<std::mutex> lk(g_mu);
     BasesBase* h = reinterpret_cast<BasesBase*>(handle);
     if (!h || h->magic != 0x6768424au) { g_err = "bad bases handle"; return GH_E_BAD_HANDLE; }
@@ -305,10 +367,10 @@ int gh_msm_resident_dev(gh_bases_t handle, const void* d_scalars, size_t n_scala
     int rc = ensure_init();
     if (rc) return rc;
     return ops->run(h, d_scalars, n_scalars, out_xyz);
-}
+} catch (...) { return gh_rt::api_exception(); }
 
 int gh_msm_resident_dev_batch(const gh_bases_t* handles, const void* const* d_scalars, const size_t* n_scalars, int count,
-                              uint64_t* out_xyz) {
+                              uint64_t* out_xyz) try {
     std::lock_guard<std::mutex> lk(g_mu);
     if (count < 0 || (count > 0 && (!handles || !d_scalars || !n_scalars || !out_xyz))) { g_err = "null argument"; return GH_E_BAD_ARG; }
     if (count == 0) return GH_OK;
@@ -329,9 +391,9 @@ int gh_msm_resident_dev_batch(const gh_bases_t* handles, const void* const* d_sc
         hipStreamSynchronize(g.stream); hipStreamSynchronize(g.stream_acc); hipStreamSynchronize(g.stream_red);
     }
     return rc;
-}
+} catch (...) { return gh_rt::api_exception(); }
 
-int gh_msm_resident(gh_bases_t handle, const uint64_t* scalars, size_t n_scalars, uint64_t* out_xyz) {
+int gh_msm_resident(gh_bases_t handle, const uint64_t* scalars, size_t n_scalars, uint64_t* out_xyz) try {
     // ONE critical section from staging the scalars to the result: the staging buffer is a shared pool slot
     std::lock_guard<std::mutex> lk(g_mu);
     BasesBase* h = reinterpret_cast<BasesBase*>(handle);
@@ -349,7 +411,7 @@ int gh_msm_resident(gh_bases_t handle, const uint64_t* scalars, size_t n_scalars
         HIPCHK(hipMemcpyAsync(d_s, scalars, n * 96, hipMemcpyHostToDevice, g.stream));
     }
     return ops->run(h, d_s, n, out_xyz);
-}
+} catch (...) { return gh_rt::api_exception(); }
 
 // ------------------------------------------------------------------------------------------
 // Content-addressed resident keys.  VariableBaseMSM::multi_scalar_mul (variable_base.rs:85-90) is a pure function of its
@@ -360,51 +422,125 @@ int gh_msm_resident(gh_bases_t handle, const uint64_t* scalars, size_t n_scalars
 // built from the `table_after`-th sighting on (default 2: what is seen twice is a proving key, what is seen once pays
 // exactly what gh_msm pays).
 namespace {
-struct KeyHash { uint64_t a, b; };
+// A key's identity: FOUR 64-bit lanes over every limb and infinity flag.  Lanes a, b select the cache entry; lanes c, d are an
+// independent pair (other multipliers, other seeds, other chunk order mixing) that a hit must ALSO match before the resident
+// copy is trusted (round 4: a 128-bit unkeyed hash alone decided a hit, so a collision returned another key's sum with status
+// 0).  All four lanes are keyed with per-process random seeds: colliding inputs cannot be prepared offline, and an accidental
+// collision needs 256 bits to agree.  What remains assumed: 2^-256.
+struct KeyHash { uint64_t a, b, c, d; };
 inline uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
-// two independent multiply-rotate lanes over 64-bit words (not cryptographic: the inputs are not adversarial, the point
-// is that equal hashes mean equal bases for any two keys a process meets)
-inline void hash_words(const uint64_t* w, size_t n, uint64_t& h1, uint64_t& h2) {
+inline void hash_words(const uint64_t* w, size_t n, uint64_t& h1, uint64_t& h2, uint64_t& h3, uint64_t& h4) {
     for (size_t i = 0; i < n; i++) {
-        h1 = rotl64((h1 ^ w[i]) * 0x9E3779B97F4A7C15ull, 29) + 0xD6E8FEB86659FD93ull;
-        h2 = (rotl64(h2, 31) + w[i]) * 0xC2B2AE3D27D4EB4Full ^ (h2 >> 33);
+        const uint64_t x = w[i];
+        h1 = rotl64((h1 ^ x) * 0x9E3779B97F4A7C15ull, 29) + 0xD6E8FEB86659FD93ull;
+        h2 = (rotl64(h2, 31) + x) * 0xC2B2AE3D27D4EB4Full ^ (h2 >> 33);
+        h3 = rotl64(h3 + x * 0xFF51AFD7ED558CCDull, 27) * 0x94D049BB133111EBull ^ x;
+        h4 = (h4 ^ rotl64(x, 17)) * 0xD1342543DE82EF95ull + (h4 >> 29);
     }
 }
+struct HashSeeds { uint64_t s[4]; };
+const HashSeeds& hash_seeds() {
+    static const HashSeeds hs = [] {
+        HashSeeds v;
+        try {
+            std::random_device rd;
+            for (auto& x : v.s) x = ((uint64_t)rd() << 32) ^ (uint64_t)rd() ^ 0x5851F42D4C957F2Dull;
+        } catch (...) {   // no entropy source: address-space layout and the clock
+            uint64_t t = (uint64_t)std::chrono::steady_clock::now().time_since_epoch().count() ^ (uint64_t)(uintptr_t)&v;
+            for (auto& x : v.s) { t = t * 6364136223846793005ull + 1442695040888963407ull; x = t; }
+        }
+        return v;
+    }();
+    return hs;
+}
+int g_test_hooks = 0;       // gh_test_hooks(): bit 0 = lanes a, b of every key identity are constant (a forced collision)
+
+// A small persistent pool for the hash (round 3 started up to 64 threads per call).  Workers are created once, on first use,
+// inside a try block: if the process cannot have them (thread limit, cgroup pids) the caller hashes its chunks inline.
+class HashPool {
+public:
+    static HashPool& get() { static HashPool* p = new HashPool(); return *p; }   // never destroyed: workers sleep until exit
+    // runs fn(c) for c in [0, n) on the workers and the calling thread
+    void run(size_t n, const std::function<void(size_t)>& fn) {
+        if (n == 0) return;
+        std::unique_lock<std::mutex> one(submit_);          // one job at a time
+        if (n == 1 || workers_ == 0) { for (size_t c = 0; c < n; c++) fn(c); return; }
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            fn_ = &fn; n_ = n; next_.store(0); pending_ = workers_; gen_++;
+        }
+        cv_.notify_all();
+        work();
+        std::unique_lock<std::mutex> lk(mu_);
+        done_.wait(lk, [&] { return pending_ == 0; });
+        fn_ = nullptr;
+    }
+private:
+    HashPool() {
+        unsigned nt = std::thread::hardware_concurrency();
+        nt = nt == 0 ? 1 : (nt > 16 ? 16 : nt);
+        for (unsigned t = 1; t < nt; t++) {
+            try {
+                std::thread([this] { loop(); }).detach();
+                workers_++;
+            } catch (...) {
+                break;
+            }
+        }
+    }
+    void work() {
+        for (;;) {
+            const size_t c = next_.fetch_add(1);
+            if (c >= n_) return;
+            (*fn_)(c);
+        }
+    }
+    void loop() {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return gen_ != seen; });
+                seen = gen_;
+            }
+            work();
+            std::lock_guard<std::mutex> lk(mu_);
+            if (--pending_ == 0) done_.notify_all();
+        }
+    }
+    std::mutex submit_, mu_;
+    std::condition_variable cv_, done_;
+    const std::function<void(size_t)>* fn_ = nullptr;
+    size_t n_ = 0;
+    std::atomic<size_t> next_{0};
+    unsigned workers_ = 0, pending_ = 0;
+    uint64_t gen_ = 0;
+};
+
 KeyHash content_hash(gh_curve_t curve, const uint64_t* bases, const uint8_t* infinity, size_t n) {
     const int deg = curve == GH_MNT4753_G2 ? 2 : (curve == GH_MNT6753_G2 ? 3 : 1);
     const size_t words = n * (size_t)24 * deg;
+    const HashSeeds& sd = hash_seeds();
     // chunks hashed in parallel, then the chunk hashes are hashed in order
     const size_t chunk = (size_t)1 << 16;
     const size_t n_chunks = (words + chunk - 1) / chunk;
-    std::vector<uint64_t> ch(2 * n_chunks + 4);
-    unsigned nt = std::thread::hardware_concurrency();
-    if (nt == 0) nt = 1;
-    if (nt > 64) nt = 64;
-    if (nt > n_chunks) nt = n_chunks ? (unsigned)n_chunks : 1;
-    auto work = [&](unsigned t) {
-        for (size_t c = t; c < n_chunks; c += nt) {
-            uint64_t h1 = 0x243F6A8885A308D3ull + c, h2 = 0x13198A2E03707344ull ^ c;
-            const size_t lo = c * chunk, len = words - lo < chunk ? words - lo : chunk;
-            hash_words(bases + lo, len, h1, h2);
-            ch[2 * c] = h1; ch[2 * c + 1] = h2;
-        }
-    };
-    if (nt <= 1) work(0);
-    else {
-        std::vector<std::thread> th;
-        for (unsigned t = 0; t < nt; t++) th.emplace_back(work, t);
-        for (auto& x : th) x.join();
-    }
-    uint64_t h1 = 0xA4093822299F31D0ull ^ (uint64_t)curve, h2 = 0x082EFA98EC4E6C89ull + n;
-    hash_words(ch.data(), 2 * n_chunks, h1, h2);
-    if (infinity) {   // flags as 0 / 1 words, eight per word; an all-zero flag array hashes like a missing one
-        uint64_t acc = 0, any = 0;
+    std::vector<uint64_t> ch(4 * n_chunks + 4);
+    HashPool::get().run(n_chunks, [&](size_t c) {
+        uint64_t h1 = sd.s[0] + c, h2 = sd.s[1] ^ c, h3 = sd.s[2] - c, h4 = sd.s[3] ^ (c * 0x9E3779B97F4A7C15ull);
+        const size_t lo = c * chunk, len = words - lo < chunk ? words - lo : chunk;
+        hash_words(bases + lo, len, h1, h2, h3, h4);
+        ch[4 * c] = h1; ch[4 * c + 1] = h2; ch[4 * c + 2] = h3; ch[4 * c + 3] = h4;
+    });
+    uint64_t h1 = sd.s[1] ^ (uint64_t)curve, h2 = sd.s[0] + n, h3 = sd.s[3] + (uint64_t)curve * 0x100000001B3ull, h4 = sd.s[2] ^ n;
+    hash_words(ch.data(), 4 * n_chunks, h1, h2, h3, h4);
+    if (infinity) {   // flags as bit words; an all-zero flag array hashes like a missing one
+        uint64_t any = 0;
         std::vector<uint64_t> fw((n + 63) / 64 + 1, 0);
         for (size_t i = 0; i < n; i++) if (infinity[i]) { fw[i >> 6] |= 1ull << (i & 63); any = 1; }
-        (void)acc;
-        if (any) hash_words(fw.data(), fw.size(), h1, h2);
+        if (any) hash_words(fw.data(), fw.size(), h1, h2, h3, h4);
     }
-    return KeyHash{h1, h2};
+    if (g_test_hooks & 1) { h1 = 0x1111111111111111ull; h2 = 0x2222222222222222ull; }
+    return KeyHash{h1, h2, h3, h4};
 }
 struct CachedKey {
     gh_curve_t curve;
@@ -418,7 +554,8 @@ struct CachedKey {
 struct KeyCache {
     std::vector<CachedKey> e;
     uint64_t clock = 0;
-    size_t max_bytes = (size_t)64 << 30;     // of the 288 GB
+    size_t max_bytes = 0;                     // 0 = not configured: half of what hipMemGetInfo reports free at the first call
+    bool budget_set = false;
     int table_after = 2;                      // build the shift table at this sighting (0 = never)
     gh_key_cache_stats_t st{};
     bool registered = false;
@@ -465,36 +602,50 @@ void cache_fit(const BasesBase* keep) {
 }
 }  // namespace
 
-uint64_t gh_bases_content_hash(gh_curve_t curve, const uint64_t* bases, const uint8_t* infinity, size_t n_bases, uint64_t* hi) {
+uint64_t gh_bases_content_hash(gh_curve_t curve, const uint64_t* bases, const uint8_t* infinity, size_t n_bases, uint64_t* hi) try {
     if (n_bases && !bases) return 0;
     const KeyHash h = content_hash(curve, bases, infinity, n_bases);
     if (hi) *hi = h.b;
     return h.a;
-}
+} catch (...) { (void)gh_rt::api_exception(); return 0; }
 
-int gh_key_cache_config(size_t max_bytes, int table_after) {
+int gh_bases_key_id(gh_curve_t curve, const uint64_t* bases, const uint8_t* infinity, size_t n_bases, uint64_t* out4) try {
+    if (!out4 || (n_bases && !bases)) { std::lock_guard<std::mutex> lk(g_mu); g_err = "null argument"; return GH_E_BAD_ARG; }
+    const KeyHash h = content_hash(curve, bases, infinity, n_bases);
+    out4[0] = h.a; out4[1] = h.b; out4[2] = h.c; out4[3] = h.d;
+    return GH_OK;
+} catch (...) { return gh_rt::api_exception(); }
+
+int gh_test_hooks(int flags) try {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_test_hooks = flags;
+    return GH_OK;
+} catch (...) { return gh_rt::api_exception(); }
+
+int gh_key_cache_config(size_t max_bytes, int table_after) try {
     std::lock_guard<std::mutex> lk(g_mu);
     if (table_after < 0) { g_err = "table_after must be >= 0"; return GH_E_BAD_ARG; }
-    kc.max_bytes = max_bytes;
+    kc.budget_set = max_bytes != GH_KEY_CACHE_AUTO;     // automatic: half of what is free at the next gh_msm_cached
+    kc.max_bytes = kc.budget_set ? max_bytes : 0;
     kc.table_after = table_after;
-    if (g.ready) cache_fit(nullptr);
+    if (g.ready && kc.budget_set) cache_fit(nullptr);
     return GH_OK;
-}
-int gh_key_cache_clear(void) {
+} catch (...) { return gh_rt::api_exception(); }
+int gh_key_cache_clear(void) try {
     std::lock_guard<std::mutex> lk(g_mu);
     if (g.ready) { hipStreamSynchronize(g.stream); hipStreamSynchronize(g.stream_acc); hipStreamSynchronize(g.stream_red); }
     cache_drop_all();
     return GH_OK;
-}
-int gh_key_cache_stats(gh_key_cache_stats_t* out) {
+} catch (...) { return gh_rt::api_exception(); }
+int gh_key_cache_stats(gh_key_cache_stats_t* out) try {
     std::lock_guard<std::mutex> lk(g_mu);
     if (!out) { g_err = "null argument"; return GH_E_BAD_ARG; }
     *out = kc.st;
     return GH_OK;
-}
+} catch (...) { return gh_rt::api_exception(); }
 
 int gh_msm_cached(gh_curve_t curve, const uint64_t* bases, const uint8_t* infinity, size_t n_bases, const uint64_t* scalars,
-                  size_t n_scalars, uint64_t* out_xyz) {
+                  size_t n_scalars, uint64_t* out_xyz) try {
     if (!out_xyz || (n_bases && !bases) || (n_scalars && !scalars)) {
         std::lock_guard<std::mutex> lk(g_mu);
         g_err = "null argument";
@@ -543,8 +694,19 @@ int gh_msm_cached(gh_curve_t curve, const uint64_t* bases, const uint8_t* infini
             kc.registered = false;
         });
     }
+    if (!kc.budget_set) {     // half of what is free now, unless gh_key_cache_config said otherwise
+        size_t free_b = 0, total_b = 0;
+        HIPCHK(hipMemGetInfo(&free_b, &total_b));
+        kc.max_bytes = free_b / 2;
+        kc.budget_set = true;
+    }
     CachedKey* hit = nullptr;
-    for (auto& k : kc.e) if (k.curve == curve && k.n == n && k.h.a == hh.a && k.h.b == hh.b) { hit = &k; break; }
+    for (auto& k : kc.e) {
+        if (k.curve != curve || k.n != n || k.h.a != hh.a || k.h.b != hh.b) continue;
+        if (k.h.c != hh.c || k.h.d != hh.d) { kc.st.collisions++; continue; }   // equal selection lanes, other content: not this key
+        hit = &k;
+        break;
+    }
     if (!hit) {
         kc.st.misses++;
         BasesBase* h = nullptr;
@@ -580,54 +742,54 @@ int gh_msm_cached(gh_curve_t curve, const uint64_t* bases, const uint8_t* infini
     if (uploader.joinable()) uploader.join();
     HIPCHK(up_err);
     return ops->run(key, d_s, n, out_xyz);
-}
+} catch (...) { return gh_rt::api_exception(); }
 
-int gh_msm_set_window(int c) {
+int gh_msm_set_window(int c) try {
     std::lock_guard<std::mutex> lk(g_mu);
     if (c < 0 || c > 24 || c == 1) { g_err = "window must be 0 (auto) or in [2, 24]"; return GH_E_BAD_ARG; }
     g.window_override = c;
     return GH_OK;
-}
-int gh_msm_set_affine(int on) {
+} catch (...) { return gh_rt::api_exception(); }
+int gh_msm_set_affine(int on) try {
     std::lock_guard<std::mutex> lk(g_mu);
     if (on < 0 || on > 2) { g_err = "affine mode must be 0 (off), 1 (on) or 2 (automatic)"; return GH_E_BAD_ARG; }
     g.affine_mode = on;
     return GH_OK;
-}
-int gh_msm_get_window(gh_curve_t curve, size_t n) {
+} catch (...) { return gh_rt::api_exception(); }
+int gh_msm_get_window(gh_curve_t curve, size_t n) try {
     std::lock_guard<std::mutex> lk(g_mu);
     return auto_window(n, curve == GH_MNT4753_G2 ? 2 : (curve == GH_MNT6753_G2 ? 3 : 1));
-}
-int gh_msm_batch_timing(int index, gh_msm_timing_t* out) {
+} catch (...) { return gh_rt::api_exception(); }
+int gh_msm_batch_timing(int index, gh_msm_timing_t* out) try {
     std::lock_guard<std::mutex> lk(g_mu);
     if (index < 0 || (size_t)index >= g.batch_tm.size()) { g_err = "no such MSM in the last batch"; return GH_E_BAD_ARG; }
     if (out) *out = g.batch_tm[(size_t)index];
     return GH_OK;
-}
-int gh_msm_last_timing(gh_msm_timing_t* out) {
+} catch (...) { return gh_rt::api_exception(); }
+int gh_msm_last_timing(gh_msm_timing_t* out) try {
     std::lock_guard<std::mutex> lk(g_mu);
     if (out) *out = g.last_msm;
     return GH_OK;
-}
+} catch (...) { return gh_rt::api_exception(); }
 
-int gh_domain_supported(gh_field_t field, size_t num_coeffs, uint32_t* log_n) {
+int gh_domain_supported(gh_field_t field, size_t num_coeffs, uint32_t* log_n) try {
     size_t size = 1;
     uint32_t lg = 0;
     while (size < num_coeffs) { size <<= 1; lg++; }
     if (log_n) *log_n = lg;
     int two_adicity = field == GH_MNT4753_FR ? GH_P6_TWO_ADICITY : GH_P4_TWO_ADICITY;
     return (int)lg < two_adicity ? 1 : 0;
-}
+} catch (...) { return gh_rt::api_exception(); }
 
-int gh_fft_dev(gh_field_t field, void* d_data, uint32_t log_n, uint32_t flags) {
+int gh_fft_dev(gh_field_t field, void* d_data, uint32_t log_n, uint32_t flags) try {
     std::lock_guard<std::mutex> lk(g_mu);
     if (!d_data) { g_err = "null argument"; return GH_E_BAD_ARG; }
     int rc = ensure_init();
     if (rc) return rc;
     return fft_run(field, d_data, log_n, flags);
-}
+} catch (...) { return gh_rt::api_exception(); }
 
-int gh_fft(gh_field_t field, const uint64_t* in, size_t n_in, uint64_t* out, uint32_t log_n, uint32_t flags) {
+int gh_fft(gh_field_t field, const uint64_t* in, size_t n_in, uint64_t* out, uint32_t log_n, uint32_t flags) try {
     if (!out || (n_in && !in)) { std::lock_guard<std::mutex> lk(g_mu); g_err = "null argument"; return GH_E_BAD_ARG; }
     if (log_n >= 31) { std::lock_guard<std::mutex> lk(g_mu); g_err = "domain too large"; return GH_E_UNSUPPORTED; }
     const size_t N = (size_t)1 << log_n;
@@ -648,19 +810,19 @@ int gh_fft(gh_field_t field, const uint64_t* in, size_t n_in, uint64_t* out, uin
     HIPCHK(hipMemcpyAsync(out, d, N * 96, hipMemcpyDeviceToHost, g.stream));
     HIPCHK(hipStreamSynchronize(g.stream));
     return GH_OK;
-}
+} catch (...) { return gh_rt::api_exception(); }
 
 int gh_witness_map_dev(gh_field_t field, void* d_a, void* d_b, void* d_c, uint32_t log_n, const uint64_t* d1,
-                       const uint64_t* d2, const uint64_t* d3, void* d_h) {
+                       const uint64_t* d2, const uint64_t* d3, void* d_h) try {
     std::lock_guard<std::mutex> lk(g_mu);
     if (!d_a || !d_b || !d_c || !d_h || !d1 || !d2 || !d3) { g_err = "null argument"; return GH_E_BAD_ARG; }
     int rc = ensure_init();
     if (rc) return rc;
     return witness_map(field, d_a, d_b, d_c, log_n, d1, d2, d3, d_h);
-}
+} catch (...) { return gh_rt::api_exception(); }
 
 int gh_witness_map(gh_field_t field, const uint64_t* a, const uint64_t* b, const uint64_t* c, uint32_t log_n,
-                   const uint64_t* d1, const uint64_t* d2, const uint64_t* d3, uint64_t* h) {
+                   const uint64_t* d1, const uint64_t* d2, const uint64_t* d3, uint64_t* h) try {
     if (!a || !b || !c || !h || !d1 || !d2 || !d3) { g_err = "null argument"; return GH_E_BAD_ARG; }
     if (log_n >= 31) { g_err = "domain too large"; return GH_E_UNSUPPORTED; }
     const size_t N = (size_t)1 << log_n, bytes = N * 96;
@@ -676,17 +838,17 @@ int gh_witness_map(gh_field_t field, const uint64_t* a, const uint64_t* b, const
     if (!rc) rc = gh_dev_download(h, dh, bytes + 96);
     gh_dev_free(da); gh_dev_free(db); gh_dev_free(dc); gh_dev_free(dh);
     return rc;
-}
+} catch (...) { return gh_rt::api_exception(); }
 
-int gh_sap_witness_map_dev(gh_field_t field, void* d_a, void* d_c, uint32_t log_n, const uint64_t* d1, const uint64_t* d2, void* d_h) {
+int gh_sap_witness_map_dev(gh_field_t field, void* d_a, void* d_c, uint32_t log_n, const uint64_t* d1, const uint64_t* d2, void* d_h) try {
     std::lock_guard<std::mutex> lk(g_mu);
     if (!d_a || !d_c || !d_h || !d1 || !d2) { g_err = "null argument"; return GH_E_BAD_ARG; }
     int rc = ensure_init();
     if (rc) return rc;
     return sap_witness_map(field, d_a, d_c, log_n, d1, d2, d_h);
-}
+} catch (...) { return gh_rt::api_exception(); }
 
-int gh_sap_witness_map(gh_field_t field, const uint64_t* a, const uint64_t* c, uint32_t log_n, const uint64_t* d1, const uint64_t* d2, uint64_t* h) {
+int gh_sap_witness_map(gh_field_t field, const uint64_t* a, const uint64_t* c, uint32_t log_n, const uint64_t* d1, const uint64_t* d2, uint64_t* h) try {
     if (!a || !c || !h || !d1 || !d2) { std::lock_guard<std::mutex> lk(g_mu); g_err = "null argument"; return GH_E_BAD_ARG; }
     if (log_n >= 31) { std::lock_guard<std::mutex> lk(g_mu); g_err = "domain too large"; return GH_E_UNSUPPORTED; }
     const size_t bytes = ((size_t)1 << log_n) * 96;
@@ -700,17 +862,17 @@ int gh_sap_witness_map(gh_field_t field, const uint64_t* a, const uint64_t* c, u
     if (!rc) rc = gh_dev_download(h, dh, bytes + 96);
     gh_dev_free(da); gh_dev_free(dc); gh_dev_free(dh);
     return rc;
-}
+} catch (...) { return gh_rt::api_exception(); }
 
-int gh_batch_inverse_dev(gh_field_t field, void* d_a, size_t n) {
+int gh_batch_inverse_dev(gh_field_t field, void* d_a, size_t n) try {
     std::lock_guard<std::mutex> lk(g_mu);
     if (n && !d_a) { g_err = "null argument"; return GH_E_BAD_ARG; }
     int rc = ensure_init();
     if (rc) return rc;
     return batch_inverse(field, d_a, n);
-}
+} catch (...) { return gh_rt::api_exception(); }
 
-int gh_batch_inverse(gh_field_t field, uint64_t* a, size_t n) {
+int gh_batch_inverse(gh_field_t field, uint64_t* a, size_t n) try {
     if (n == 0) return GH_OK;
     if (!a) { std::lock_guard<std::mutex> lk(g_mu); g_err = "null argument"; return GH_E_BAD_ARG; }
     void* da = nullptr;
@@ -720,18 +882,18 @@ int gh_batch_inverse(gh_field_t field, uint64_t* a, size_t n) {
     if (!rc) rc = gh_dev_download(a, da, n * 96);
     gh_dev_free(da);
     return rc;
-}
+} catch (...) { return gh_rt::api_exception(); }
 
-int gh_lagrange_coefficients_dev(gh_field_t field, uint32_t log_n, const uint64_t* tau12, void* d_out) {
+int gh_lagrange_coefficients_dev(gh_field_t field, uint32_t log_n, const uint64_t* tau12, void* d_out) try {
     std::lock_guard<std::mutex> lk(g_mu);
     if (!tau12 || !d_out) { g_err = "null argument"; return GH_E_BAD_ARG; }
     if (log_n >= 31) { g_err = "domain too large"; return GH_E_UNSUPPORTED; }
     int rc = ensure_init();
     if (rc) return rc;
     return lagrange_coefficients(field, log_n, tau12, d_out);
-}
+} catch (...) { return gh_rt::api_exception(); }
 
-int gh_lagrange_coefficients(gh_field_t field, uint32_t log_n, const uint64_t* tau12, uint64_t* out) {
+int gh_lagrange_coefficients(gh_field_t field, uint32_t log_n, const uint64_t* tau12, uint64_t* out) try {
     if (!tau12 || !out) { std::lock_guard<std::mutex> lk(g_mu); g_err = "null argument"; return GH_E_BAD_ARG; }
     if (log_n >= 31) { std::lock_guard<std::mutex> lk(g_mu); g_err = "domain too large"; return GH_E_UNSUPPORTED; }
     const size_t bytes = ((size_t)1 << log_n) * 96;
@@ -741,13 +903,13 @@ int gh_lagrange_coefficients(gh_field_t field, uint32_t log_n, const uint64_t* t
     if (!rc) rc = gh_dev_download(out, d, bytes);
     gh_dev_free(d);
     return rc;
-}
+} catch (...) { return gh_rt::api_exception(); }
 
-int gh_fft_last_kernel_ms(float* ms) {
+int gh_fft_last_kernel_ms(float* ms) try {
     std::lock_guard<std::mutex> lk(g_mu);
     if (ms) *ms = g.last_fft_ms;
     return GH_OK;
-}
+} catch (...) { return gh_rt::api_exception(); }
 
 static int vec_dispatch(gh_field_t field, int op, void* d_a, const void* d_b, const uint64_t* s, size_t n) {
     std::lock_guard<std::mutex> lk(g_mu);
@@ -760,7 +922,7 @@ int gh_vec_mul_dev(gh_field_t field, void* d_a, const void* d_b, size_t n) { ret
 int gh_vec_sub_dev(gh_field_t field, void* d_a, const void* d_b, size_t n) { return vec_dispatch(field, 1, d_a, d_b, nullptr, n); }
 int gh_vec_scale_dev(gh_field_t field, void* d_a, const uint64_t* scalar12, size_t n) { return vec_dispatch(field, 2, d_a, nullptr, scalar12, n); }
 
-int gh_vec_mul(gh_field_t field, uint64_t* a, const uint64_t* b, size_t n) {
+int gh_vec_mul(gh_field_t field, uint64_t* a, const uint64_t* b, size_t n) try {
     if (n == 0) return GH_OK;
     if (!a || !b) { g_err = "null argument"; return GH_E_BAD_ARG; }
     void *da = nullptr, *db = nullptr;
@@ -774,8 +936,8 @@ int gh_vec_mul(gh_field_t field, uint64_t* a, const uint64_t* b, size_t n) {
     gh_dev_free(da);
     gh_dev_free(db);
     return rc;
-}
-int gh_vec_scale(gh_field_t field, uint64_t* a, const uint64_t* scalar12, size_t n) {
+} catch (...) { return gh_rt::api_exception(); }
+int gh_vec_scale(gh_field_t field, uint64_t* a, const uint64_t* scalar12, size_t n) try {
     if (n == 0) return GH_OK;
     if (!a || !scalar12) { g_err = "null argument"; return GH_E_BAD_ARG; }
     void* da = nullptr;
@@ -786,23 +948,23 @@ int gh_vec_scale(gh_field_t field, uint64_t* a, const uint64_t* scalar12, size_t
     if (!rc) rc = gh_dev_download(a, da, n * 96);
     gh_dev_free(da);
     return rc;
-}
+} catch (...) { return gh_rt::api_exception(); }
 
-int gh_dev_alloc(void** d_ptr, size_t bytes) {
+int gh_dev_alloc(void** d_ptr, size_t bytes) try {
     std::lock_guard<std::mutex> lk(g_mu);
     if (!d_ptr) { g_err = "null argument"; return GH_E_BAD_ARG; }
     int rc = ensure_init();
     if (rc) return rc;
     HIPCHK(hipMalloc(d_ptr, bytes ? bytes : 1));
     return GH_OK;
-}
-int gh_dev_free(void* d_ptr) {
+} catch (...) { return gh_rt::api_exception(); }
+int gh_dev_free(void* d_ptr) try {
     std::lock_guard<std::mutex> lk(g_mu);
     if (!d_ptr) return GH_OK;
     HIPCHK(hipFree(d_ptr));
     return GH_OK;
-}
-int gh_dev_upload(void* d_dst, const void* h_src, size_t bytes) {
+} catch (...) { return gh_rt::api_exception(); }
+int gh_dev_upload(void* d_dst, const void* h_src, size_t bytes) try {
     std::lock_guard<std::mutex> lk(g_mu);
     if (!bytes) return GH_OK;
     if (!d_dst || !h_src) { g_err = "null argument"; return GH_E_BAD_ARG; }
@@ -811,8 +973,8 @@ int gh_dev_upload(void* d_dst, const void* h_src, size_t bytes) {
     HIPCHK(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, g.stream));
     HIPCHK(hipStreamSynchronize(g.stream));
     return GH_OK;
-}
-int gh_dev_download(void* h_dst, const void* d_src, size_t bytes) {
+} catch (...) { return gh_rt::api_exception(); }
+int gh_dev_download(void* h_dst, const void* d_src, size_t bytes) try {
     std::lock_guard<std::mutex> lk(g_mu);
     if (!bytes) return GH_OK;
     if (!h_dst || !d_src) { g_err = "null argument"; return GH_E_BAD_ARG; }
@@ -821,8 +983,8 @@ int gh_dev_download(void* h_dst, const void* d_src, size_t bytes) {
     HIPCHK(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, g.stream));
     HIPCHK(hipStreamSynchronize(g.stream));
     return GH_OK;
-}
-int gh_dev_trim(void) {
+} catch (...) { return gh_rt::api_exception(); }
+int gh_dev_trim(void) try {
     std::lock_guard<std::mutex> lk(g_mu);
     if (!g.ready) return GH_OK;
     HIPCHK(hipStreamSynchronize(g.stream));
@@ -830,41 +992,41 @@ int gh_dev_trim(void) {
     HIPCHK(hipStreamSynchronize(g.stream_red));
     pool_release("");
     return GH_OK;
-}
-int gh_dev_sync(void) {
+} catch (...) { return gh_rt::api_exception(); }
+int gh_dev_sync(void) try {
     std::lock_guard<std::mutex> lk(g_mu);
     int rc = ensure_init();
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(g.stream));
     return GH_OK;
-}
+} catch (...) { return gh_rt::api_exception(); }
 
-int gh_proj_add(gh_curve_t curve, uint64_t* acc_xyz, const uint64_t* p_xyz) {
+int gh_proj_add(gh_curve_t curve, uint64_t* acc_xyz, const uint64_t* p_xyz) try {
     if (!acc_xyz || !p_xyz) { g_err = "null argument"; return GH_E_BAD_ARG; }
     const MsmOps* ops = ops_of(curve);
     if (!ops) return GH_E_BAD_ARG;
     return ops->proj_add(acc_xyz, p_xyz);
-}
+} catch (...) { return gh_rt::api_exception(); }
 
-int gh_proj_mul(gh_curve_t curve, const uint64_t* p_xyz, const uint64_t* scalar12, uint64_t* out_xyz) {
+int gh_proj_mul(gh_curve_t curve, const uint64_t* p_xyz, const uint64_t* scalar12, uint64_t* out_xyz) try {
     if (!p_xyz || !scalar12 || !out_xyz) { g_err = "null argument"; return GH_E_BAD_ARG; }
     const MsmOps* ops = ops_of(curve);
     if (!ops) return GH_E_BAD_ARG;
     return ops->proj_mul(p_xyz, scalar12, out_xyz);
-}
+} catch (...) { return gh_rt::api_exception(); }
 
-int gh_proj_neg(gh_curve_t curve, uint64_t* xyz) {
+int gh_proj_neg(gh_curve_t curve, uint64_t* xyz) try {
     if (!xyz) { g_err = "null argument"; return GH_E_BAD_ARG; }
     const MsmOps* ops = ops_of(curve);
     if (!ops) return GH_E_BAD_ARG;
     return ops->proj_neg(xyz);
-}
+} catch (...) { return gh_rt::api_exception(); }
 
-int gh_proj_to_affine(gh_curve_t curve, const uint64_t* xyz, uint64_t* out_xy, uint8_t* is_infinity) {
+int gh_proj_to_affine(gh_curve_t curve, const uint64_t* xyz, uint64_t* out_xy, uint8_t* is_infinity) try {
     if (!xyz || !out_xy || !is_infinity) { g_err = "null argument"; return GH_E_BAD_ARG; }
     const MsmOps* ops = ops_of(curve);
     if (!ops) return GH_E_BAD_ARG;
     return ops->to_affine(xyz, out_xy, is_infinity);
-}
+} catch (...) { return gh_rt::api_exception(); }
 
 }  // extern "C"

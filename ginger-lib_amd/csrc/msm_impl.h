@@ -120,7 +120,7 @@ int upload_bases(const uint64_t* bases, const uint8_t* infinity, size_t n, int c
         HIPCHK(hipMalloc(&h->d_points, n * sizeof(Aff<C>)));
         HIPCHK(hipMalloc(&d_in, in_bytes));
         HIPCHK(hipMemcpyAsync(d_in, bases, in_bytes, hipMemcpyHostToDevice, g.stream));
-        hipLaunchKernelGGL((msm_convert_bases_kernel<C>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, g.stream,
+        GH_LAUNCH((msm_convert_bases_kernel<C>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, g.stream,
                            (const uint32_t*)d_in, (Aff<C>*)h->d_points, n, canonical);
         HIPCHK(hipGetLastError());
         if (infinity) {
@@ -196,6 +196,17 @@ int precompute_bases(BasesBase* h, int c_req, int max_rows) {
         HIPCHK(hipMemGetInfo(&free_b, &total_b));
     }
     if (need > free_b) { g_err = "not enough device memory for the precomputed table"; return GH_E_NOMEM; }
+    if (const char* t = getenv("GH_TEST_TABLE_NOMEM"); t && atoi(t) != 0) {
+        // fault injection (include/ginger_hip.h gh_test_hooks): the path a table build takes when the card is full -- every pooled
+        // scratch buffer is dropped, the key stays on the per-window path.  tests/test_gpu_parity.py runs gh_msm_cached through it
+        // on every GPU run (the round-3 fault: a pooled scalar buffer freed here under a running copy).
+        HIPCHK(hipStreamSynchronize(g.stream));
+        HIPCHK(hipStreamSynchronize(g.stream_acc));
+        HIPCHK(hipStreamSynchronize(g.stream_red));
+        pool_release("");
+        g_err = "not enough device memory for the precomputed table (GH_TEST_TABLE_NOMEM)";
+        return GH_E_NOMEM;
+    }
     Aff<C>* table = nullptr;
     FT *zs = nullptr, *zp = nullptr;
     uint32_t* bad = nullptr;
@@ -210,6 +221,12 @@ int precompute_bases(BasesBase* h, int c_req, int max_rows) {
     for (size_t i0 = 0; i0 < n && e == hipSuccess; i0 += slab) {
         const size_t cnt = n - i0 < slab ? n - i0 : slab;
         static const bool pre_jac = !(getenv("GH_PRE_JAC") && atoi(getenv("GH_PRE_JAC")) == 0);
+        {   // the table builders carry 2-9 KB of stack per lane: no dispatch the card cannot back with scratch (runtime.h scratch_guard)
+            const void* kfn = !pre_jac ? (const void*)(msm_precompute_kernel<C>)
+                              : (C::F::DEG == 1 ? (const void*)(msm_precompute_jac_kernel<C, typename C::F>)
+                                                : (const void*)(msm_precompute_jac_kernel<C, typename C::FC>));
+            if (int grc = scratch_guard(kfn, (cnt + 255) / 256 * 256)) { hipFree(table); return grc; }
+        }
         if (pre_jac) {
             if constexpr (C::F::DEG == 1)
                 hipLaunchKernelGGL((msm_precompute_jac_kernel<C, typename C::F>), dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st,
@@ -442,10 +459,9 @@ struct MsmJob {
         // (measured at 2^20 + 1 buckets: L1 = 16 -> 6.2 ms, 8 -> 6.8, 4 -> 8.2, 32 -> 7.9 -- the one bucket beyond the power of two
         //  added a 1025th / 2049th / 4097th wave program, which ran beside or after another one on its SIMD and doubled the
         //  launch; with the merged set at exactly 2^(c-1) slots level 1 takes 4.3 ms (L1 = 16), level 2 1.1 ms).
-        static const bool split_reduce_off = getenv("GH_NO_SPLIT_REDUCE") != nullptr;
         tpw = 64;
-        if (C::F::DEG == 2 && !split_reduce_off) tpw = 32;     // lane pairs  (msm_kernels.h 5b)
-        if (C::F::DEG == 3 && !split_reduce_off) tpw = 16;     // lane triples, 48 lanes busy
+        if (C::F::DEG == 2) tpw = 32;     // lane pairs  (msm_kernels.h 5b); the one-lane G2 programs (6-14 KB of stack per lane) are no longer built
+        if (C::F::DEG == 3) tpw = 16;     // lane triples, 48 lanes busy
         sw = tpw == 64 ? 6 : (tpw == 32 ? 5 : 4);
         auto programs = [&](int l1) { return (size_t)RW * ((Q + (uint32_t)tpw * l1 - 1) / ((uint32_t)tpw * l1)); };
         L1 = MSM_REDUCE_L;
@@ -568,34 +584,34 @@ struct MsmJob {
             if ((rc = pool_get(nm, cells * 4, (void**)&block_off))) return rc;
             snprintf(nm, sizeof nm, "part_pairs#%d", slot);
             if ((rc = pool_get(nm, entries * 8, (void**)&part))) return rc;
-            hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+            GH_LAUNCH(msm_digits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
                                (const uint32_t*)d_scalars, (const uint8_t*)h->d_inf, n, c, W, win_stride, top_unsigned, scalar_modulus<C>(), digits,
                                (uint32_t*)nullptr, agg_iters, merged ? 1u : 0u, (uint32_t)sets);
             HIPCHK(hipMemsetAsync(block_hist + (cells - 1), 0, 4, st));
-            hipLaunchKernelGGL(msm_part_hist_kernel, dim3(a.n_blocks), dim3(MSM_PART_THREADS), 0, st, a, block_hist);
+            GH_LAUNCH(msm_part_hist_kernel, dim3(a.n_blocks), dim3(MSM_PART_THREADS), 0, st, a, block_hist);
             HIPCHK(hipGetLastError());
             snprintf(nm, sizeof nm, "scan_tmp3#%d", slot);
             if ((rc = device_scan(block_hist, block_off, cells, nm, st))) return rc;
-            hipLaunchKernelGGL(msm_part_scatter_kernel, dim3(a.n_blocks), dim3(MSM_PART_THREADS), 0, st, a, (const uint32_t*)block_off, part);
-            hipLaunchKernelGGL(msm_bin_sort_kernel, dim3(a.n_bins), dim3(MSM_BIN_THREADS), (size_t)4 << bin_shift, st, (const uint2*)part,
+            GH_LAUNCH(msm_part_scatter_kernel, dim3(a.n_blocks), dim3(MSM_PART_THREADS), 0, st, a, (const uint32_t*)block_off, part);
+            GH_LAUNCH(msm_bin_sort_kernel, dim3(a.n_bins), dim3(MSM_BIN_THREADS), (size_t)4 << bin_shift, st, (const uint2*)part,
                                (const uint32_t*)block_off, a.n_blocks, bin_shift, (uint32_t)total, counts, starts, sorted, sort_ordered ? 1u : 0u);
             HIPCHK(hipGetLastError());
         } else {
             HIPCHK(hipMemsetAsync(counts, 0, total * 4, st));
-            hipLaunchKernelGGL(msm_digits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+            GH_LAUNCH(msm_digits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
                                (const uint32_t*)d_scalars, (const uint8_t*)h->d_inf, n, c, W, win_stride, top_unsigned, scalar_modulus<C>(), digits, counts, agg_iters,
                                merged ? 1u : 0u, (uint32_t)sets);
             HIPCHK(hipGetLastError());
             if ((rc = device_scan(counts, starts, total, "scan_tmp", st))) return rc;
             HIPCHK(hipMemcpyAsync(cursor, starts, total * 4, hipMemcpyDeviceToDevice, st));
         }
-        hipLaunchKernelGGL(msm_size_hist_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, counts, total, heavy_thr, size_hist, plan + 4);
+        GH_LAUNCH(msm_size_hist_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, counts, total, heavy_thr, size_hist, plan + 4);
         if ((rc = device_scan(size_hist, size_cursor, MSM_SIZE_BINS, "scan_tmp2", st))) return rc;
-        hipLaunchKernelGGL(msm_size_scatter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, counts, total, heavy_thr, size_cursor, order);
-        hipLaunchKernelGGL(msm_heavy_plan_kernel, dim3(1), dim3(1), 0, st, (const uint32_t*)size_hist, (const uint32_t*)counts,
+        GH_LAUNCH(msm_size_scatter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, counts, total, heavy_thr, size_cursor, order);
+        GH_LAUNCH(msm_heavy_plan_kernel, dim3(1), dim3(1), 0, st, (const uint32_t*)size_hist, (const uint32_t*)counts,
                            (const uint32_t*)order, (const uint32_t*)starts, (uint32_t)total, heavy_chunk, chunk_start, plan);
         if (!use_part)
-            hipLaunchKernelGGL(msm_scatter_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)W), dim3(256), 0, st,
+            GH_LAUNCH(msm_scatter_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)W), dim3(256), 0, st,
                                (const int32_t*)digits, n, W, win_stride, merged ? (uint32_t)h->n : 0u, cursor, sorted, agg_iters, merged ? 1u : 0u,
                                (uint32_t)sets);
         HIPCHK(hipGetLastError());
@@ -630,15 +646,14 @@ struct MsmJob {
         {
             // one launch: the chunks of the heavy buckets first, then every other bucket, longest first
             const size_t tasks = (size_t)n_chunks + (total - n_heavy);
-            static const bool no_split = getenv("GH_NO_SPLIT") != nullptr;
             // G2: one coefficient per lane, 2 (Fq2) / 3 (Fq3) lanes per task (msm_kernels.h 4b)
             constexpr bool is_g2 = std::is_same<C, Mnt4G2>::value || std::is_same<C, Mnt6G2>::value;
             if constexpr (is_g2) {
-                if (!no_split) {
+                {
                     typedef typename std::conditional<std::is_same<C, Mnt4G2>::value, F2S<P4, 13, GH_F2S_DUAL != 0>, F3S<P6, 11, GH_F3S_TRIPLE>>::type FS;
                     constexpr int LANES = FS::LANES;
                     const size_t waves = (tasks + (64 / LANES) - 1) / (64 / LANES);
-                    hipLaunchKernelGGL((msm_accumulate_split_kernel<C, FS, LANES>), dim3((unsigned)((waves * 64 + 255) / 256)), dim3(256), 0, st,
+                    GH_LAUNCH((msm_accumulate_split_kernel<C, FS, LANES>), dim3((unsigned)((waves * 64 + 255) / 256)), dim3(256), 0, st,
                                        (const Aff<C>*)src_points, (const uint32_t*)sorted, (const uint32_t*)starts,
                                        (const uint32_t*)counts, (const uint32_t*)order, (uint32_t)total, (const Aff<C>*)salts, buckets,
                                        (const uint32_t*)chunk_start, n_heavy, n_chunks, heavy_chunk, partials);
@@ -654,38 +669,40 @@ struct MsmJob {
                     gh_asm::AccTask* tk = nullptr;
                     snprintf(nm, sizeof nm, "acc_tasks#%d", slot);
                     if ((rc = pool_get(nm, tasks * sizeof(gh_asm::AccTask), (void**)&tk))) return rc;
-                    hipLaunchKernelGGL((msm_acc_tasks_kernel<C>), dim3((unsigned)((tasks + 255) / 256)), dim3(256), 0, st,
+                    GH_LAUNCH((msm_acc_tasks_kernel<C>), dim3((unsigned)((tasks + 255) / 256)), dim3(256), 0, st,
                                        (const uint32_t*)starts, (const uint32_t*)counts, (const uint32_t*)order, (uint32_t)total, buckets,
                                        (const uint32_t*)chunk_start, n_heavy, n_chunks, heavy_chunk, partials, (AccTaskRec*)tk);
                     if ((rc = gh_asm::acc_g1_launch(std::is_same<typename C::PF, P6>::value ? 6 : 4, src_points, (const uint32_t*)sorted, tk,
                                                     salts, (uint32_t)tasks, st))) return rc;
                     done_xyzz = true;
                 } else if (acc_xyzz && acc_waves >= 2) {
-                    hipLaunchKernelGGL((msm_accumulate_xyzz_kernel<C>), dim3((unsigned)((tasks + 255) / 256)), dim3(256), 0, st,
+                    GH_LAUNCH((msm_accumulate_xyzz_kernel<C>), dim3((unsigned)((tasks + 255) / 256)), dim3(256), 0, st,
                                        (const Aff<C>*)src_points, (const uint32_t*)sorted, (const uint32_t*)starts,
                                        (const uint32_t*)counts, (const uint32_t*)order, (uint32_t)total, (const Aff<C>*)salts, buckets,
                                        (const uint32_t*)chunk_start, n_heavy, n_chunks, heavy_chunk, partials, 0u, 0u);
                     done_xyzz = true;
                 }
             }
-            if (!(is_g2 && !no_split) && !done_xyzz) {
+            if constexpr (!is_g2) {      // (the one-lane G2 instances, 4-8 KB of stack per lane, are no longer built: G2 is always split)
+            if (!done_xyzz) {
                 if (acc_waves >= 2)
-                    hipLaunchKernelGGL((msm_accumulate_kernel<C, 2>), dim3((unsigned)((tasks + 255) / 256)), dim3(256), 0, st,
+                    GH_LAUNCH((msm_accumulate_kernel<C, 2>), dim3((unsigned)((tasks + 255) / 256)), dim3(256), 0, st,
                                        (const Aff<C>*)src_points, (const uint32_t*)sorted, (const uint32_t*)starts,
                                        (const uint32_t*)counts, (const uint32_t*)order, (uint32_t)total, (const Aff<C>*)salts, buckets,
                                        (const uint32_t*)chunk_start, n_heavy, n_chunks, heavy_chunk, partials);
                 else
-                    hipLaunchKernelGGL((msm_accumulate_kernel<C, 1>), dim3((unsigned)((tasks + 255) / 256)), dim3(256), 0, st,
+                    GH_LAUNCH((msm_accumulate_kernel<C, 1>), dim3((unsigned)((tasks + 255) / 256)), dim3(256), 0, st,
                                        (const Aff<C>*)src_points, (const uint32_t*)sorted, (const uint32_t*)starts,
                                        (const uint32_t*)counts, (const uint32_t*)order, (uint32_t)total, (const Aff<C>*)salts, buckets,
                                        (const uint32_t*)chunk_start, n_heavy, n_chunks, heavy_chunk, partials);
+            }
             }
         }
         }
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(g.pev[es][3], st));
         if (n_heavy > 0) {   // one wave per heavy bucket adds its chunk sums
-            hipLaunchKernelGGL((msm_heavy_combine_kernel<C>), dim3(n_heavy), dim3(64), lds_wave, st, (const Proj<C>*)partials,
+            GH_LAUNCH((msm_heavy_combine_kernel<C>), dim3(n_heavy), dim3(64), lds_wave, st, (const Proj<C>*)partials,
                                (const uint32_t*)order, (const uint32_t*)chunk_start, buckets);
             HIPCHK(hipGetLastError());
         }
@@ -730,7 +747,7 @@ struct MsmJob {
     if ((rc = pool_get(nm, bytes, (void**)&ptr))) return rc;
         POOLT("aff_cnt", aff_cnt, (size_t)R * stride * 4)
         POOLT("aff_st", aff_st, (size_t)R * stride * 4)
-        hipLaunchKernelGGL(aff_counts_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+        GH_LAUNCH(aff_counts_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
                            (const uint32_t*)counts, (uint32_t)total, R, stride, aff_cnt);
         snprintf(nm, sizeof nm, "aff_scan#%d", slot);
         for (int r = 1; r <= R; r++)
@@ -762,7 +779,7 @@ struct MsmJob {
         uint32_t *d_bq, *d_tab;
         POOLT("aff_bq", d_bq, ((size_t)K + 2) * 4)
         POOLT("aff_tab", d_tab, ((size_t)K + 2) * (R + 1) * 4)
-        hipLaunchKernelGGL(aff_chunks_kernel, dim3((K + 1 + 63) / 64), dim3(64), 0, st, (const uint32_t*)starts, (const uint32_t*)counts,
+        GH_LAUNCH(aff_chunks_kernel, dim3((K + 1 + 63) / 64), dim3(64), 0, st, (const uint32_t*)starts, (const uint32_t*)counts,
                            (const uint32_t*)aff_st, (const uint32_t*)aff_cnt, (uint32_t)total, R, stride, K, d_bq, d_tab);
         HIPCHK(hipGetLastError());
         std::vector<uint32_t> bq((size_t)K + 1), tab(((size_t)K + 1) * (R + 1));
@@ -811,7 +828,7 @@ struct MsmJob {
                     const uint32_t* m_in = r == 0 ? counts : aff_cnt + (size_t)(r - 1) * stride;
                     unsigned dgrid = (n_out + 255) / 256;
                     if (dgrid > 16384) dgrid = 16384;
-                    hipLaunchKernelGGL(aff_desc_kernel, dim3(dgrid), dim3(256), 0, st, st_in, m_in,
+                    GH_LAUNCH(aff_desc_kernel, dim3(dgrid), dim3(256), 0, st, st_in, m_in,
                                        (const uint32_t*)(aff_st + (size_t)r * stride), (uint32_t)total, T(j, r + 1), n_out, desc + doff);
                     uint32_t waves = (n_out + TPW * (uint32_t)env_bmin - 1) / (TPW * (uint32_t)env_bmin);
                     if (waves > max_waves) waves = max_waves;
@@ -819,8 +836,8 @@ struct MsmJob {
                     AffRoundArgs<C> a;
                     a.rows = rows; a.in = in; a.sorted = r == 0 ? sorted : nullptr; a.desc = desc + doff; a.n_out = n_out; a.in_base = T(j, r);
                     a.prefix = prefix; a.out = out; a.stage1 = stage1; a.stage2 = stage2; a.groups = waves * TPW; a.bmin = (uint32_t)env_bmin;
-                    if (r == 0) hipLaunchKernelGGL((aff_round_kernel<C, FS, true>), dim3(waves / 4), dim3(256), 0, st, a);
-                    else hipLaunchKernelGGL((aff_round_kernel<C, FS, false>), dim3(waves / 4), dim3(256), 0, st, a);
+                    if (r == 0) GH_LAUNCH((aff_round_kernel<C, FS, true>), dim3(waves / 4), dim3(256), 0, st, a);
+                    else GH_LAUNCH((aff_round_kernel<C, FS, false>), dim3(waves / 4), dim3(256), 0, st, a);
                 }
                 doff += n_out;
                 in = out;
@@ -831,13 +848,13 @@ struct MsmJob {
             const uint32_t* stR = aff_st + (size_t)(R - 1) * stride;
             const uint32_t* mR = aff_cnt + (size_t)(R - 1) * stride;
             if constexpr (C::F::DEG == 1) {
-                hipLaunchKernelGGL((msm_accumulate_xyzz_kernel<C, true>), dim3((nbk + 255) / 256), dim3(256), 0, st, (const Aff<C>*)in,
+                GH_LAUNCH((msm_accumulate_xyzz_kernel<C, true>), dim3((nbk + 255) / 256), dim3(256), 0, st, (const Aff<C>*)in,
                                    (const uint32_t*)nullptr, stR, mR, (const uint32_t*)nullptr, nbk, (const Aff<C>*)salts, buckets,
                                    (const uint32_t*)nullptr, 0u, 0u, heavy_chunk, (Proj<C>*)nullptr, bq[j], T(j, R));
             } else {
                 typedef typename std::conditional<C::F::DEG == 2, F2S<P4, 13, GH_F2S_DUAL != 0>, F3S<P6, 11, GH_F3S_TRIPLE>>::type FA;
                 const size_t fwaves = ((size_t)nbk + TPW - 1) / TPW;
-                hipLaunchKernelGGL((msm_accumulate_split_kernel<C, FA, LANES, true>), dim3((unsigned)((fwaves * 64 + 255) / 256)), dim3(256), 0, st,
+                GH_LAUNCH((msm_accumulate_split_kernel<C, FA, LANES, true>), dim3((unsigned)((fwaves * 64 + 255) / 256)), dim3(256), 0, st,
                                    (const Aff<C>*)in, (const uint32_t*)nullptr, stR, mR, (const uint32_t*)nullptr, nbk, (const Aff<C>*)salts, buckets,
                                    (const uint32_t*)nullptr, 0u, 0u, heavy_chunk, (Proj<C>*)nullptr, bq[j], T(j, R));
             }
@@ -870,13 +887,14 @@ struct MsmJob {
                 snprintf(nm, sizeof nm, "reduce_slabs#%d", slot);
                 int rc = pool_get(nm, (size_t)(nb1 > nb2 ? nb1 : nb2) * P3Slab::WORDS * 4, (void**)&slabs);
                 if (rc) return rc;
-                hipLaunchKernelGGL((msm_wave_reduce_split_kernel<C, FS, LANES, TPW>), dim3(nb1), dim3(64), lds_split, st,
+                GH_LAUNCH((msm_wave_reduce_split_kernel<C, FS, LANES, TPW>), dim3(nb1), dim3(64), lds_split, st,
                                    i0, none, none, nb1, 1u, segs_per_window, L1, (const Aff<C>*)salts, seg_out, slabs);
-                hipLaunchKernelGGL((msm_wave_reduce_split_kernel<C, FS, LANES, TPW>), dim3(nb2), dim3(64), lds_split, st,
+                GH_LAUNCH((msm_wave_reduce_split_kernel<C, FS, LANES, TPW>), dim3(nb2), dim3(64), lds_split, st,
                                    r0, r1, r2, (uint32_t)RW, 3u, 1u, L2, (const Aff<C>*)salts, win_out, slabs);
                 launched = true;
             }
         }
+        if constexpr (C::F::DEG == 1) {
         if (!launched) {
             // the programs' accumulators live in a slab of global memory each (msm_kernels.h, ReduceSlab)
             uint32_t* slabs = nullptr;
@@ -899,27 +917,28 @@ struct MsmJob {
                 WaveReduceIn<C> l0{lane_out, 2, 0, lanes_per_window, 0, all}, l1{lane_out, 2, 1, lanes_per_window, 1, all};
                 const unsigned nb2l = (unsigned)(2 * RW);
                 if (one_wave) {
-                    hipLaunchKernelGGL((msm_wave_reduce_kernel<C, 1>), dim3((nb1 + wpb - 1) / wpb), dim3(64 * wpb), lds_wave * wpb, st,
+                    GH_LAUNCH((msm_wave_reduce_kernel<C, 1>), dim3((nb1 + wpb - 1) / wpb), dim3(64 * wpb), lds_wave * wpb, st,
                                        i0l, none, none, nb1, 1u, segs_per_window, L1, (const Aff<C>*)salts, lane_out, slabs);
-                    hipLaunchKernelGGL((msm_wave_reduce_kernel<C, 1>), dim3((nb2l + wpb - 1) / wpb), dim3(64 * wpb), lds_wave * wpb, st,
+                    GH_LAUNCH((msm_wave_reduce_kernel<C, 1>), dim3((nb2l + wpb - 1) / wpb), dim3(64 * wpb), lds_wave * wpb, st,
                                        l0, l1, none, (uint32_t)RW, 2u, 1u, (int)segs_per_window, (const Aff<C>*)salts, win_out, slabs);
                 } else {
-                    hipLaunchKernelGGL((msm_wave_reduce_kernel<C, 2>), dim3((nb1 + wpb - 1) / wpb), dim3(64 * wpb), lds_wave * wpb, st,
+                    GH_LAUNCH((msm_wave_reduce_kernel<C, 2>), dim3((nb1 + wpb - 1) / wpb), dim3(64 * wpb), lds_wave * wpb, st,
                                        i0l, none, none, nb1, 1u, segs_per_window, L1, (const Aff<C>*)salts, lane_out, slabs);
-                    hipLaunchKernelGGL((msm_wave_reduce_kernel<C, 2>), dim3((nb2l + wpb - 1) / wpb), dim3(64 * wpb), lds_wave * wpb, st,
+                    GH_LAUNCH((msm_wave_reduce_kernel<C, 2>), dim3((nb2l + wpb - 1) / wpb), dim3(64 * wpb), lds_wave * wpb, st,
                                        l0, l1, none, (uint32_t)RW, 2u, 1u, (int)segs_per_window, (const Aff<C>*)salts, win_out, slabs);
                 }
             } else if (one_wave) {
-                hipLaunchKernelGGL((msm_wave_reduce_kernel<C, 1>), dim3((nb1 + wpb - 1) / wpb), dim3(64 * wpb), lds_wave * wpb, st,
+                GH_LAUNCH((msm_wave_reduce_kernel<C, 1>), dim3((nb1 + wpb - 1) / wpb), dim3(64 * wpb), lds_wave * wpb, st,
                                    i0, none, none, nb1, 1u, segs_per_window, L1, (const Aff<C>*)salts, seg_out, slabs);
-                hipLaunchKernelGGL((msm_wave_reduce_kernel<C, 1>), dim3((nb2 + wpb - 1) / wpb), dim3(64 * wpb), lds_wave * wpb, st,
+                GH_LAUNCH((msm_wave_reduce_kernel<C, 1>), dim3((nb2 + wpb - 1) / wpb), dim3(64 * wpb), lds_wave * wpb, st,
                                    r0, r1, r2, (uint32_t)RW, 3u, 1u, L2, (const Aff<C>*)salts, win_out, slabs);
             } else {
-                hipLaunchKernelGGL((msm_wave_reduce_kernel<C, 2>), dim3((nb1 + wpb - 1) / wpb), dim3(64 * wpb), lds_wave * wpb, st,
+                GH_LAUNCH((msm_wave_reduce_kernel<C, 2>), dim3((nb1 + wpb - 1) / wpb), dim3(64 * wpb), lds_wave * wpb, st,
                                    i0, none, none, nb1, 1u, segs_per_window, L1, (const Aff<C>*)salts, seg_out, slabs);
-                hipLaunchKernelGGL((msm_wave_reduce_kernel<C, 2>), dim3((nb2 + wpb - 1) / wpb), dim3(64 * wpb), lds_wave * wpb, st,
+                GH_LAUNCH((msm_wave_reduce_kernel<C, 2>), dim3((nb2 + wpb - 1) / wpb), dim3(64 * wpb), lds_wave * wpb, st,
                                    r0, r1, r2, (uint32_t)RW, 3u, 1u, L2, (const Aff<C>*)salts, win_out, slabs);
             }
+        }
         }
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(g.pev[es][5], st));
@@ -993,11 +1012,11 @@ int accumulate_lists(const void* points, const uint32_t* sorted, const uint32_t*
       if (gh_asm::enabled()) {
         gh_asm::AccTask* tk = nullptr;
         if (int rc = pool_get("acc_tasks#lists", (size_t)total * sizeof(gh_asm::AccTask), (void**)&tk)) return rc;
-        hipLaunchKernelGGL((msm_acc_tasks_kernel<C>), dim3((unsigned)(((size_t)total + 255) / 256)), dim3(256), 0, st, starts, counts, order,
+        GH_LAUNCH((msm_acc_tasks_kernel<C>), dim3((unsigned)(((size_t)total + 255) / 256)), dim3(256), 0, st, starts, counts, order,
                            total, (Proj<C>*)out_proj, (const uint32_t*)nullptr, 0u, 0u, 0u, (Proj<C>*)nullptr, (AccTaskRec*)tk);
         if (int rc = gh_asm::acc_g1_launch(std::is_same<typename C::PF, P6>::value ? 6 : 4, points, sorted, tk, salts, total, st)) return rc;
       } else {
-        hipLaunchKernelGGL((msm_accumulate_xyzz_kernel<C>), dim3((unsigned)(((size_t)total + 255) / 256)), dim3(256), 0, st,
+        GH_LAUNCH((msm_accumulate_xyzz_kernel<C>), dim3((unsigned)(((size_t)total + 255) / 256)), dim3(256), 0, st,
                            (const Aff<C>*)points, sorted, starts, counts, order, total, (const Aff<C>*)salts, (Proj<C>*)out_proj,
                            (const uint32_t*)nullptr, 0u, 0u, 0u, (Proj<C>*)nullptr, 0u, 0u);
       }
@@ -1005,7 +1024,7 @@ int accumulate_lists(const void* points, const uint32_t* sorted, const uint32_t*
         typedef typename std::conditional<std::is_same<C, Mnt4G2>::value, F2S<P4, 13, GH_F2S_DUAL != 0>, F3S<P6, 11, GH_F3S_TRIPLE>>::type FS;
         constexpr int LANES = FS::LANES;
         const size_t waves = ((size_t)total + (64 / LANES) - 1) / (64 / LANES);
-        hipLaunchKernelGGL((msm_accumulate_split_kernel<C, FS, LANES>), dim3((unsigned)((waves * 64 + 255) / 256)), dim3(256), 0, st,
+        GH_LAUNCH((msm_accumulate_split_kernel<C, FS, LANES>), dim3((unsigned)((waves * 64 + 255) / 256)), dim3(256), 0, st,
                            (const Aff<C>*)points, sorted, starts, counts, order, total, (const Aff<C>*)salts, (Proj<C>*)out_proj,
                            (const uint32_t*)nullptr, 0u, 0u, 0u, (Proj<C>*)nullptr);
     }

@@ -44,6 +44,7 @@ struct Ctx {
     gh_msm_timing_t last_msm{};
     std::vector<gh_msm_timing_t> batch_tm;   // per-MSM timings of the last batch call
     float last_fft_ms = 0;
+    size_t scratch_reserved = 0;        // scratch_guard(): stack-frame scratch the runtime already holds for this context's queues
     std::vector<std::function<void()>> at_shutdown;   // releases of function-local device / pinned allocations
 };
 
@@ -58,6 +59,26 @@ void pool_release(const char* prefix);             // free every cached buffer w
 int device_scan(const uint32_t* in, uint32_t* out, size_t n, const char* tmpname, hipStream_t stream = nullptr);   // nullptr: g.stream
 int auto_window(size_t n, int deg);
 void dist_teardown_locked();                      // dist.hip: gh_shutdown (API lock held) destroys the communicator with the context
+
+// No C++ exception leaves the library (include/ginger_hip.h: "nothing is thrown"; the reference's multi_scalar_mul is
+// infallible, variable_base.rs:85-90, and the Rust shim falls back to the CPU path on a non-zero status): every extern "C"
+// entry point is a function-try-block whose handler returns api_exception() -- std::bad_alloc -> GH_E_NOMEM, anything else
+// -> GH_E_HIP, the message in gh_last_error().  Called from inside a catch handler only.
+int api_exception() noexcept;
+
+// Kernels with KB-scale stack frames (the out-of-line EC functions of the cold paths: 2-17 KB per lane, build/*.log) make the
+// runtime reserve frame x 64 lanes x resident waves of scratch at dispatch -- up to 9 GB for the MNT6 G2 instances -- and a
+// reservation that fails does so inside the runtime's queue handler, which ends the process (the round-3 abort inside
+// gh_msm_cached with 640 MB free: DESIGN.md section 9-4b).  scratch_guard() asks the code object for the kernel's frame and
+// refuses the launch with GH_E_NOMEM when the card cannot hold the reservation; GH_LAUNCH is hipLaunchKernelGGL behind it.
+int scratch_guard(const void* kernel, size_t threads);
+#define GH_LAUNCH(kern, grid, block, shmem, st, ...)                                                              \
+    do {                                                                                                          \
+        const dim3 g_ = (grid), b_ = (block);                                                                     \
+        if (int rc_ = gh_rt::scratch_guard((const void*)(kern), (size_t)g_.x * g_.y * g_.z * b_.x * b_.y * b_.z)) \
+            return rc_;                                                                                           \
+        hipLaunchKernelGGL(kern, g_, b_, shmem, st, __VA_ARGS__);                                                 \
+    } while (0)
 
 #define HIPCHK(call)                                                                         \
     do {                                                                                     \

@@ -129,23 +129,37 @@ int gh_msm_resident(gh_bases_t handle, const uint64_t* scalars, size_t n_scalars
 /* ---- content-addressed resident keys: the drop-in for an UNCHANGED caller of VariableBaseMSM::multi_scalar_mul
  * (algebra/src/msm/variable_base.rs:85-90), which hands over (bases, scalars) slices on every call.
  * gh_msm_cached has gh_msm's signature and gh_msm's result -- a pure function of its arguments -- but remembers the
- * bases it has seen: they are identified by a 128-bit hash over EVERY coordinate limb and infinity flag of the first
- * min(n_bases, n_scalars) bases (never by address: a buffer reused for other bases is another key), a repeat moves only
- * the scalars, a new key is uploaded like gh_msm does.  From the table_after-th sighting of a key (default 2; >= 4096 bases)
- * its shift table (gh_bases_precompute) is built.  The cache is bounded: least recently used keys are freed once the
- * device bytes held exceed max_bytes (default 64 GiB); it is emptied by gh_key_cache_clear and by gh_shutdown.
+ * bases it has seen: they are identified by FOUR 64-bit hash lanes over EVERY coordinate limb and infinity flag of the first
+ * min(n_bases, n_scalars) bases (never by address: a buffer reused for other bases is another key).  Two lanes select the
+ * cache entry, the other two -- an independent pair -- must match as well before the resident copy is used; all four are keyed
+ * with per-process random seeds, so colliding inputs cannot be prepared in advance.  Residual assumption: two different
+ * base vectors do not agree in all 256 bits (`collisions` counts entries that agreed in the first 128 only: they are misses).
+ * A repeat moves only the scalars, a new key is uploaded like gh_msm does.  From the table_after-th sighting of a key
+ * (default 2; >= 4096 bases) its shift table (gh_bases_precompute) is built; if the table cannot be built (memory) the key
+ * stays on the per-window path and the call still succeeds.  The cache is bounded: least recently used keys are freed once
+ * the device bytes held exceed max_bytes (default: half of what hipMemGetInfo reports free at the first call); it is
+ * emptied by gh_key_cache_clear and by gh_shutdown.
  * rust/algebra-hip-sys binds multi_scalar_mul to this entry point.                                  */
 typedef struct {
     uint64_t entries, bytes;          /* keys resident now, device bytes they hold (points + flags + shift tables) */
     uint64_t hits, misses, evictions, tables_built;
+    uint64_t collisions;              /* lookups that matched an entry's selection lanes but not its verification lanes */
 } gh_key_cache_stats_t;
 int gh_msm_cached(gh_curve_t curve, const uint64_t* bases, const uint8_t* infinity, size_t n_bases,
                   const uint64_t* scalars, size_t n_scalars, uint64_t* out_xyz);
+#define GH_KEY_CACHE_AUTO ((size_t)-1)   /* max_bytes: half of what hipMemGetInfo reports free at the next gh_msm_cached */
 int gh_key_cache_config(size_t max_bytes, int table_after /* 0 = never build tables */);
 int gh_key_cache_clear(void);
 int gh_key_cache_stats(gh_key_cache_stats_t* out);
 /* The hash gh_msm_cached keys on (low half returned, high half through *hi if not NULL).  Host-only: needs no device. */
 uint64_t gh_bases_content_hash(gh_curve_t curve, const uint64_t* bases, const uint8_t* infinity, size_t n_bases, uint64_t* hi);
+/* All four lanes of a key's identity: out4[0..1] select the cache entry, out4[2..3] verify it.  Host-only.  Values differ
+ * from process to process (random seeds); within a process equal content gives equal lanes. */
+int gh_bases_key_id(gh_curve_t curve, const uint64_t* bases, const uint8_t* infinity, size_t n_bases, uint64_t* out4);
+/* Fault injection for the test-suite (0 = off; never set by a product caller).  bit 0: the selection lanes of every key
+ * identity are constant, i.e. every key collides with every other of its size.  The environment variable
+ * GH_TEST_TABLE_NOMEM=1 makes every shift-table build take its out-of-memory path (scratch pool dropped, GH_E_NOMEM). */
+int gh_test_hooks(int flags);
 /* scalars already in device memory (from gh_dev_alloc); used by the benchmark's HBM-resident timing
  * and by a device-resident prover pipeline.  The call is synchronous on the library stream. */
 int gh_msm_resident_dev(gh_bases_t handle, const void* d_scalars, size_t n_scalars, uint64_t* out_xyz);

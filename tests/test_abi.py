@@ -90,10 +90,37 @@ def test_key_cache_identifies_bases_by_content(gl):
         assert gl.bases_content_hash(curve, buf, inf) != hz
     assert gl.bases_content_hash("mnt4753_g1", np.zeros((4, 24), np.uint64)) != gl.bases_content_hash("mnt6753_g1", np.zeros((4, 24), np.uint64))
     st = gl.key_cache_stats()
-    assert set(st) == {"entries", "bytes", "hits", "misses", "evictions", "tables_built"}
+    assert set(st) == {"entries", "bytes", "hits", "misses", "evictions", "tables_built", "collisions"}
     gl.key_cache_config(1 << 30, 0)
     gl.key_cache_clear()
     gl.key_cache_config()
+
+
+def test_key_identity_has_verification_lanes_that_survive_a_forced_collision(gl):
+    """A hit of gh_msm_cached needs all FOUR 64-bit lanes of the key identity to agree: two select the cache entry, an
+    independent pair verifies it (round 3 trusted 128 unkeyed bits: a collision returned another key's sum with status 0).
+    gh_test_hooks(1) makes the selection lanes of every key constant -- the forced collision; the verification lanes must
+    still tell any two base vectors apart.  Host-only; the device-side consequence (a miss, the right sum, `collisions`
+    counted) is tests/test_gpu_parity.py::test_msm_cached_survives_forced_hash_collisions_and_a_failed_table_build."""
+    rng = np.random.default_rng(11)
+    n = 5000
+    a = rng.integers(0, 1 << 63, size=(n, 24), dtype=np.uint64)
+    b = a.copy()
+    b[n // 2, 5] ^= np.uint64(1 << 40)
+    ida, idb = gl.bases_key_id("mnt4753_g1", a), gl.bases_key_id("mnt4753_g1", b)
+    assert ida == gl.bases_key_id("mnt4753_g1", a.copy())
+    assert gl.bases_content_hash("mnt4753_g1", a) == ida[:2]
+    assert all(x != y for x, y in zip(ida, idb))                # every lane sees the flipped bit
+    gl.set_test_hooks(1)
+    try:
+        fa, fb = gl.bases_key_id("mnt4753_g1", a), gl.bases_key_id("mnt4753_g1", b)
+        assert fa[:2] == fb[:2]                                 # the forced collision of the selection lanes
+        assert fa[2:] == ida[2:] and fb[2:] == idb[2:] and fa[2:] != fb[2:]
+        fc = gl.bases_key_id("mnt6753_g1", a)
+        assert fc[:2] == fa[:2] and fc[2:] != fa[2:]            # the curve is part of the verified identity
+    finally:
+        gl.set_test_hooks(0)
+    assert gl.bases_key_id("mnt4753_g1", a) == ida
 
 
 def test_compute_fails_loudly_without_gpu(gl):

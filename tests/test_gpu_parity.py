@@ -684,6 +684,75 @@ def test_msm_cached_is_a_pure_function_of_its_arguments(gpu):
     assert gpu.key_cache_stats()["entries"] == 0
 
 
+def test_msm_cached_survives_forced_hash_collisions_and_a_failed_table_build(gpu):
+    """Two round-3 defects of gh_msm_cached, exercised by fault injection on every GPU run instead of by filling the card
+    (the test that did that aborted the suite once and was deleted):
+    (a) a shift-table build that runs out of memory drops every pooled scratch buffer -- GH_TEST_TABLE_NOMEM=1 makes every
+        build take exactly that path (msm_impl.h precompute_bases).  The scalars' PCIe copy is in flight at that moment; round 3
+        copied into a pooled buffer that the builder freed under the copy (GPU fault at 2^22 MNT6 G2 pairs).  The call must
+        succeed on the per-window path with the oracle's sum, `tables_built` unchanged;
+    (b) a hit used to be decided by 128 hash bits alone.  gh_test_hooks(1) forces the selection lanes of every key to one
+        value: different bases of one size must still be different keys (verification lanes), each with its own sum."""
+    gpu.key_cache_clear()
+    gpu.key_cache_config(None, 2)
+
+    def aff(curve, x):
+        xy, inf = gpu.proj_to_affine(curve, x)
+        return inf, xy.tobytes()
+
+    def oaff(curve, b, s):
+        xy, inf = S.oracle_affine(curve, S.oracle_msm(curve, b, None, s, 16))
+        return inf, xy.tobytes()
+
+    os.environ["GH_TEST_TABLE_NOMEM"] = "1"
+    try:
+        for curve, n in (("mnt4753_g1", 1 << 13), ("mnt6753_g2", 1 << 12)):
+            C = pyref.CURVES[curve]
+            buf, _ = S.bases_array(C, S.chain_points(C, n, pyref.Rng(31)))
+            base = gpu.key_cache_stats()
+            for k in range(3):                                        # sighting 2 and 3 both try the table and fall back
+                s = S.random_scalars_np(n, seed=80 + k, below=C.order)
+                assert aff(curve, gpu.msm_cached(curve, buf, s)) == oaff(curve, buf, s)
+                tm = gpu.msm_last_timing()
+                assert tm["num_windows"] == 752 // tm["window_bits"] + 1          # the per-window path
+            st = gpu.key_cache_stats()
+            assert (st["misses"] - base["misses"], st["hits"] - base["hits"], st["tables_built"] - base["tables_built"]) == (1, 2, 0)
+    finally:
+        del os.environ["GH_TEST_TABLE_NOMEM"]
+    # without the injected failure the same bases, seen afresh, get their table at the second sighting
+    gpu.key_cache_clear()
+    base = gpu.key_cache_stats()
+    for k in range(2):
+        s = S.random_scalars_np(n, seed=90 + k, below=C.order)
+        assert aff(curve, gpu.msm_cached(curve, buf, s)) == oaff(curve, buf, s)
+    assert gpu.key_cache_stats()["tables_built"] - base["tables_built"] == 1
+    gpu.key_cache_clear()
+
+    curve = "mnt4753_g1"
+    C = pyref.CURVES[curve]
+    n = 1 << 12
+    a, _ = S.bases_array(C, S.chain_points(C, n, pyref.Rng(41)))
+    b, _ = S.bases_array(C, S.chain_points(C, n, pyref.Rng(42)))
+    s = S.random_scalars_np(n, seed=95, below=C.order)
+    ea, eb = oaff(curve, a, s), oaff(curve, b, s)
+    assert ea != eb
+    gpu.set_test_hooks(1)
+    try:
+        assert gpu.bases_key_id(curve, a)[:2] == gpu.bases_key_id(curve, b)[:2]
+        base = gpu.key_cache_stats()
+        assert aff(curve, gpu.msm_cached(curve, a, s)) == ea           # miss
+        assert aff(curve, gpu.msm_cached(curve, b, s)) == eb           # collides with a's entry: verified, rejected, miss
+        assert aff(curve, gpu.msm_cached(curve, a, s)) == ea           # hit (table)
+        assert aff(curve, gpu.msm_cached(curve, b, s)) == eb           # hit behind a colliding entry
+        st = gpu.key_cache_stats()
+        assert (st["misses"] - base["misses"], st["hits"] - base["hits"], st["entries"]) == (2, 2, 2)
+        assert st["collisions"] - base["collisions"] >= 2
+    finally:
+        gpu.set_test_hooks(0)
+        gpu.key_cache_clear()
+        gpu.key_cache_config()
+
+
 def test_msm_parity_again_with_the_lean_reduction_forced(gpu):
     """Inside a pipelined batch of large MSMs the bucket reduction runs in its lane-level form (msm_impl.h: `lean`; level 1 hands
     every lane's two sums to level 2).  Sizes the oracle can referee never reach it by themselves, so the MSM parity tests of

@@ -41,7 +41,7 @@ def test_every_c_function_is_declared_once_with_the_same_arity():
             n_r = 0 if not rust[name].strip() else rust[name].count(",") + 1
             assert n_c == n_r, (name, n_c, n_r)
             n_total += 1
-    assert n_total == len(rust) == 69
+    assert n_total == len(rust) == 71
 
 
 def test_constants_and_timing_struct_match_the_header():
@@ -60,12 +60,17 @@ def test_constants_and_timing_struct_match_the_header():
     assert re.search(r"#define GH_FFT_INVERSE 1u", h) and "pub const FFT_INVERSE: u32 = 1;" in lib
     assert re.search(r"#define GH_FFT_COSET 2u", h) and "pub const FFT_COSET: u32 = 2;" in lib
     # gh_msm_timing_t, field by field
-    body = re.search(r"typedef struct \{(.*?)\} gh_msm_timing_t;", h, flags=re.S).group(1)
+    body = re.search(r"typedef struct \{([^{}]*)\} gh_msm_timing_t;", h, flags=re.S).group(1)
     c_fields = [(t.strip(), n) for t, n in re.findall(r"([\w ]+?)\s+(\w+);", body)]
     rbody = re.search(r"pub struct GhMsmTiming \{(.*?)\}", lib, flags=re.S).group(1)
     r_fields = re.findall(r"pub (\w+): (\w+),", rbody)
     cmap = {"float": "f32", "int": "c_int", "unsigned long long": "u64", "unsigned int": "u32"}
     assert [(n, cmap[t]) for t, n in c_fields] == r_fields
+    # gh_key_cache_stats_t: all u64, same names in the same order
+    body = re.search(r"typedef struct \{([^{}]*)\} gh_key_cache_stats_t;", h, flags=re.S).group(1)
+    c_names = [n for decl in re.findall(r"uint64_t\s+([^;]+);", body) for n in re.split(r"\s*,\s*", decl.strip())]
+    rbody = re.search(r"pub struct GhKeyCacheStats \{(.*?)\}", strip_comments(lib.replace("///", "//")), flags=re.S).group(1)
+    assert re.findall(r"pub (\w+): (\w+),", rbody) == [(n, "u64") for n in c_names] and len(c_names) == 7
 
 
 def test_patch_hooks_the_reference_entry_points():
