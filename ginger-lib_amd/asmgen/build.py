@@ -10,7 +10,7 @@ import os
 import subprocess
 import sys
 
-from . import g1_xyzz
+from . import g1_xyzz, g2_rounds
 from .isa import module_text
 
 LLVM = os.environ.get("GH_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
@@ -25,6 +25,15 @@ def programs():
         g1_xyzz.build("gh_asm_acc_g1_p4", P4, R % P4),
         g1_xyzz.build("gh_asm_acc_g1_p6", P6, R % P6),
     ]
+    # the affine rounds of the G2 MSMs: forward / backward kernel of round 0 and of the later rounds, per tower
+    c2 = g2_rounds.Cfg(2, 13, P4, R % P4)          # MNT4-753 G2: Fq2 = Fq[u] / (u^2 - 13)   (fields/mnt4753/fq2.rs:19)
+    c3 = g2_rounds.Cfg(3, 11, P6, R % P6)          # MNT6-753 G2: Fq3 = Fq[u] / (u^3 - 11)   (fields/mnt6753/fq3.rs)
+    for tag, cfg in (("f2", c2), ("f3", c3)):
+        for fwd in (True, False):
+            for r0 in (True, False):
+                progs.append(g2_rounds.build("gh_asm_aff_%s_%s_%s" % (tag, "fwd" if fwd else "bwd", "r0" if r0 else "rn"), cfg, fwd, r0))
+    if os.environ.get("GH_ASM_DEBUG"):          # stage markers for tools/asm_g2_check.py (not shipped)
+        progs.append(g2_rounds.build("gh_asm_aff_f2_bwd_r0_dbg", c2, False, True, debug=True))
     if os.environ.get("GH_ASM_VARIANTS"):      # A/B variants of the gather for tools/asm_mb/acc_run.hip (not shipped)
         progs += [g1_xyzz.build("gh_asm_acc_g1_p4_s1", P4, R % P4, split=1),
                   g1_xyzz.build("gh_asm_acc_g1_p4_s2", P4, R % P4, split=2),

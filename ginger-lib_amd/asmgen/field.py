@@ -194,6 +194,108 @@ class FieldGen:
                 yield from self._close_high(chx, m, k)
         yield from self.cond_sub(chx, m, dd, m if dst is None else dst)
 
+    def triple(self, chx, chy, pairs, m, dd, dst=None):
+        """dst = (a b + c d + e f) 2^-754 mod p for pairs = [(a, b), (c, d), (e, f)] with ONE reduction (fp29.h fp_mul3, which
+        restates the Karatsuba-free schoolbook form of fields/models/fp3.rs:453-477 coefficient by coefficient).  A column holds up to
+        104 products of 58 bits: it does not fit 64 bits, so two chains each take half (X = a b + c d + carry-in, Y = e f + m p,
+        at most 52 products + 2^36 each) and are joined with a carry bit when the column closes.  Operands need normalised limbs
+        only (< 2^29); the value is below (3 p^2 + R p) / R < 2.33 p, which can exceed 2^754 by one bit: `top`, folded into
+        the first of two conditional subtractions.  dd: scratch slot for them (may be an operand: the columns are done)."""
+        g = self.g
+        (a, b), (c, d), (e, f) = pairs
+        X, Y = chx.acc, chy.acc
+        fx = True
+        for k in range(2 * NL):
+            lo = max(0, k - NL + 1)
+            hi = min(k, NL - 1)
+            xs, ys = [], []
+            for i in range(lo, hi + 1):
+                xs.append((a.sub(i), b.sub(k - i)))
+                xs.append((c.sub(i), d.sub(k - i)))
+                ys.append((e.sub(i), f.sub(k - i)))
+            mlo = 0 if k < NL else k - NL + 1
+            mhi = k - 1 if k < NL else NL - 1
+            for i in range(mlo, mhi + 1):
+                ys.append((m.sub(i), self.sP(k - i)))
+            fy = True
+            ix = iy = 0
+            while ix < len(xs) or iy < len(ys):                    # alternate the chains: no mad waits for its predecessor
+                if ix < len(xs):
+                    x, y = xs[ix]; ix += 1
+                    g.v_mad_u64_u32(X, chx.sdum, x, y, 0 if fx else X); fx = False; yield
+                if iy < len(ys):
+                    x, y = ys[iy]; iy += 1
+                    g.v_mad_u64_u32(Y, chy.sdum, x, y, 0 if fy else Y); fy = False; yield
+                if ix < len(xs) and len(xs) - ix > len(ys) - iy:   # X has twice the product terms: catch up
+                    x, y = xs[ix]; ix += 1
+                    g.v_mad_u64_u32(X, chx.sdum, x, y, 0 if fx else X); fx = False; yield
+            if k == 2 * NL - 1:                                     # only the carry of column 50
+                g.v_and_b32(m.sub(NL - 1), S(self.s_lm), X.lo()); yield
+                g.v_lshrrev_b32(chy.t1, LB, X.lo()); yield          # top
+                break
+            if k < NL:
+                if fy:                                              # k == 0 has e f, so Y is never empty here
+                    raise AssertionError
+                g.v_add_u32(chx.t0, X.lo(), Y.lo()); yield
+                g.v_mul_lo_u32(chx.t0, chx.t0, S(self.s_inv)); yield
+                g.v_and_b32(m.sub(k), S(self.s_lm), chx.t0); yield
+                g.v_mad_u64_u32(Y, chy.sdum, m.sub(k), self.sP(0), Y); yield
+            g.v_add_co_u32(X.lo(), chx.scar, X.lo(), Y.lo()); yield
+            g.v_addc_co_u32(X.hi(), chx.scar, X.hi(), Y.hi(), chx.scar); yield
+            g.v_cndmask_b32(chx.t1, 0, 8, chx.scar); yield         # bit 64 of the column lands on bit 35 of the carry
+            if k >= NL:
+                g.v_and_b32(m.sub(k - NL), S(self.s_lm), X.lo()); yield
+            g.v_alignbit_b32(X.lo(), X.hi(), X.lo(), LB); yield
+            g.v_lshrrev_b32(X.hi(), LB, X.hi()); yield
+            g.v_or_b32(X.hi(), X.hi(), chx.t1); yield
+        # value = m + top 2^754 < 2.33 p: subtract p where top is set or m >= p, then the usual conditional subtraction
+        bw, x = chx.t1, chx.t0
+        for i in range(NL):
+            if i == 0:
+                g.v_add_u32(x, self.sNP(0), m.sub(0)); yield
+            else:
+                g.v_add3_u32(x, m.sub(i), self.sNP(i), bw); yield
+            g.v_ashrrev_i32(bw, 31, x); yield
+            g.v_and_b32(dd.sub(i), S(self.s_lm), x); yield
+        g.v_cmp_eq_u32(chx.scar, 0, bw); yield
+        g.v_cmp_ne_u32(chy.scar, 0, chy.t1); yield
+        g.s_or_b64(chx.scar, chx.scar, chy.scar); yield
+        for i in range(NL):
+            g.v_cndmask_b32(m.sub(i), m.sub(i), dd.sub(i), chx.scar); yield
+        yield from self.cond_sub(chx, m, dd, m if dst is None else dst)
+
+    def mul_small(self, ch, x, k, dst, s_invc):
+        """dst = k x - q p with q = floor(k x_25 / (p_25 + 1)), k a per-lane VGPR in [1, 16) (fp29.h fp_mul_small_rt without its
+        final conditional subtraction): the value is k x mod p or that plus p, below p + 27 2^725 -- an operand for products
+        only (their column bounds have 2^57 of slack for a top limb that exceeds p_25 by 27; a sum of two such products stays
+        below 2 p R).  k = 1 returns x.  s_invc: S pair holding the double 1 / (p_25 + 1).  dst may alias x."""
+        g = self.g
+        acc, t0, nq = ch.acc, ch.t0, ch.t1
+        g.v_mul_lo_u32(t0, x.sub(NL - 1), k); yield
+        g.v_cvt_f64_u32(acc, t0); yield
+        g.v_add_f64(acc, acc, "0.5"); yield                         # (v + 1/2) / c is never within 2^-29 of an integer: the rounded
+        g.v_mul_f64(acc, acc, s_invc); yield                        # product truncates to floor(v / c) exactly
+        g.v_cvt_u32_f64(nq, acc); yield
+        g.v_sub_u32(nq, 0, nq); yield
+        for i in range(NL):
+            g.v_mad_i64_i32(acc, ch.sdum, x.sub(i), k, 0 if i == 0 else acc); yield
+            g.v_mad_i64_i32(acc, ch.sdum, nq, self.sP(i), acc); yield
+            g.v_and_b32(dst.sub(i), S(self.s_lm), acc.lo()); yield
+            if i + 1 < NL:
+                g.v_alignbit_b32(acc.lo(), acc.hi(), acc.lo(), LB); yield
+                g.v_ashrrev_i32(acc.hi(), LB, acc.hi()); yield
+
+    def invc_bits(self):
+        """the double 1 / (p_25 + 1) as (lo, hi) words"""
+        import struct
+        lo, hi = struct.unpack("<II", struct.pack("<d", 1.0 / (self.pl[NL - 1] + 1)))
+        return lo, hi
+
+    def bperm(self, dst, addr, src):
+        """dst = src of the lane addr / 4 (ds_bpermute_b32: LDS crossbar, no LDS memory); the caller waits on lgkmcnt"""
+        for i in range(NL):
+            self.g.ds_bpermute_b32(dst.sub(i), addr, src.sub(i)); yield
+
     # ------------------------------------------------------------------ add / sub / neg
     def sub(self, ch, a, b, dst):
         """dst = a - b mod p (a, b in [0, p)).  dst may alias a or b."""

@@ -15,7 +15,7 @@ The prime, -p, the Montgomery constant and the limb mask live in SGPRs.
 Products are issued in PAIRS, interleaved instruction by instruction on the two chains:
   (U2 || S2)  P, W  (PP || RR)  park RR  (PPP || ZZ3)  (Q || ZZZ3)  X3, T  dual(W T + V PPP)
 """
-from .isa import Prog, V, S, VCC, EXEC, OFF
+from .isa import Prog, V, S, VCC, EXEC, OFF, fix_hazards
 from .field import FieldGen, Chain, interleave, run, NL, LM
 
 AFF_BYTES = 2 * NL * 4          # 208
@@ -300,4 +300,5 @@ def build(name, p, one_mont, prefetch=False, split=4):
     g.s_andn2_b64(EXEC, S_SAVE, S_DETOUR)
     g.s_cbranch_execz(L_ADV)
     g.long_branch(L_DET_RET, S_JMP)
+    g.hazard_nops = fix_hazards(g)      # isa.py: the gfx950 VALU -> SGPR -> VALU wait states
     return g

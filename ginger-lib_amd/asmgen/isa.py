@@ -267,3 +267,104 @@ def module_text(progs):
     out.append("...")
     out.append("\t.end_amdgpu_metadata")
     return "\n".join(out) + "\n", infos
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# gfx940 / gfx950 data hazards that the hardware does not interlock (LLVM GCNHazardRecognizer::checkVALUHazards, the
+# hasVDecCoExecHazard() block -- hipcc pads the same places with s_nop):
+#   * a VALU instruction writes an SGPR (v_cmp, carry-out, v_readfirstlane) or VCC -> a VALU instruction reads that SGPR / VCC
+#     (select mask, carry-in, scalar source): 2 wait states in between;
+#   * a VALU instruction writes a VGPR -> v_readlane / v_readfirstlane reads it: 1 wait state;
+#   * a VALU instruction writes a VGPR -> a DPP instruction reads it: 2 wait states (all of GFX9).
+# A wait state is one issued instruction of the wave (s_nop N counts N + 1).  Found on the card: a v_readfirstlane right behind
+# the shift that made its operand read the register's OLD value in one kernel and the new one in its twin with identical code.
+# fix_hazards() pads a finished program with the s_nop the rules ask for; labels are joins: the padding after a label assumes
+# the worst predecessor (a writer right before the branch, the branch being one wait state).
+CARRY_OUT_OPS = {"v_add_co_u32", "v_addc_co_u32", "v_sub_co_u32", "v_subb_co_u32", "v_subrev_co_u32", "v_subbrev_co_u32",
+                 "v_mad_u64_u32", "v_mad_i64_i32"}
+SGPR_WAIT, READLANE_WAIT, DPP_WAIT = 2, 1, 2
+
+
+def _sregs(o):
+    if isinstance(o, Reg) and o.kind in ("s", "vcc"):
+        return range(o.idx, o.idx + o.n)
+    return ()
+
+
+def _vregs(o):
+    if isinstance(o, Reg) and o.kind in ("v", "a"):
+        base = o.idx + (256 if o.kind == "a" else 0)
+        return range(base, base + o.n)
+    return ()
+
+
+def _wait_states(i):
+    if i.op in ("label", "comment"):
+        return 0
+    if i.op == "s_nop":
+        return int(i.args[0]) + 1
+    if i.op == "long_branch":
+        return 4
+    return 1
+
+
+def hazard_scan(prog, fix):
+    """returns (list of findings, new instruction list); fix: insert the missing wait states"""
+    out, found = [], []
+    pos = 0
+    s_write, v_write = {}, {}        # register -> wait-state position of the last VALU write
+    join = None                      # position of the last label: stands for a VALU write of every register right before the branch
+    for i in prog.ins:
+        if i.op == "label":
+            join = pos
+            out.append(i)
+            continue
+        if i.op == "comment":
+            out.append(i)
+            continue
+        valu = i.op.startswith("v_")
+        need = 0
+        if valu:
+            if i.op in ("v_cmp_eq_u32",) or i.op.startswith("v_cmp_") or i.op in ("v_readfirstlane_b32", "v_readlane_b32"):
+                wr_s, srcs = list(_sregs(i.args[0])), i.args[1:]
+            elif i.op in CARRY_OUT_OPS:
+                wr_s, srcs = list(_sregs(i.args[1])), i.args[2:]
+            else:
+                wr_s, srcs = [], i.args[1:]
+            wr_v = list(_vregs(i.args[0]))
+            for o in srcs:
+                for r in _sregs(o):
+                    last = s_write.get(r)
+                    if join is not None and (last is None or join - 1 > last):
+                        last = join - 1
+                    if last is not None:
+                        need = max(need, SGPR_WAIT - (pos - last - 1))
+            vwait = READLANE_WAIT if i.op in ("v_readfirstlane_b32", "v_readlane_b32") else (DPP_WAIT if i.op.endswith("_dpp") else 0)
+            if vwait:
+                for o in srcs:
+                    for r in _vregs(o):
+                        last = v_write.get(r)
+                        if join is not None and (last is None or join - 1 > last):
+                            last = join - 1
+                        if last is not None:
+                            need = max(need, vwait - (pos - last - 1))
+        if need > 0:
+            found.append((len(out), i.op, need))
+            if fix:
+                out.append(Ins("s_nop", (need - 1,), {}))
+                pos += need
+        out.append(i)
+        if valu:
+            for r in wr_s:
+                s_write[r] = pos
+            for r in wr_v:
+                v_write[r] = pos
+        pos += _wait_states(i)
+    return found, out
+
+
+def fix_hazards(prog):
+    """pads prog in place; returns the number of s_nop inserted"""
+    found, out = hazard_scan(prog, True)
+    prog.ins = out
+    return len(found)

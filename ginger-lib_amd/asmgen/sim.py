@@ -729,3 +729,98 @@ def _ds_write2st64(w, i):
     for d, key in ((d0, "offset0"), (d1, "offset1")):
         idx, em = _lds_idx(w, addr, int(i.mods.get(key, 0)) * 256, 4)
         w.lds[idx[em]] = w.V[w.ridx(d)][em]
+
+
+# ------------------------------------------------------------------ round 4: ops of the G2 round kernels (g2_rounds.py)
+@op("v_mad_i64_i32")
+def _mad_i64(w, i):
+    d, sd, a, b, c = i.args
+    x = np.asarray(np.broadcast_to(w.rd(a), (LANES,))).astype(np.int32).astype(np.int64)
+    y = np.asarray(np.broadcast_to(w.rd(b), (LANES,))).astype(np.int32).astype(np.int64)
+    c64 = np.asarray(np.broadcast_to(w.rd64(c), (LANES,)), dtype=U64).astype(np.int64)
+    res = x * y + c64
+    w.wr64(d, res.astype(U64))
+    w.wr_lanemask(sd, np.zeros(LANES, dtype=bool))
+
+
+def _f64_src(w, o):
+    if isinstance(o, str):
+        return np.float64(float(o))
+    if isinstance(o, Reg):
+        return np.asarray(np.broadcast_to(w.rd64(o), (LANES,)), dtype=U64).view(np.float64)
+    return np.float64(o)
+
+
+@op("v_cvt_f64_u32")
+def _cvt_f64_u32(w, i):
+    d, a = i.args
+    w.wr64(d, np.asarray(np.broadcast_to(w.rd(a), (LANES,))).astype(np.float64).view(U64))
+
+
+@op("v_add_f64")
+def _add_f64(w, i):
+    d, a, b = i.args
+    w.wr64(d, np.asarray(np.broadcast_to(_f64_src(w, a) + _f64_src(w, b), (LANES,)), dtype=np.float64).view(U64))
+
+
+@op("v_mul_f64")
+def _mul_f64(w, i):
+    d, a, b = i.args
+    w.wr64(d, np.asarray(np.broadcast_to(_f64_src(w, a) * _f64_src(w, b), (LANES,)), dtype=np.float64).view(U64))
+
+
+@op("v_cvt_u32_f64")
+def _cvt_u32_f64(w, i):
+    d, a = i.args
+    v = np.trunc(np.asarray(np.broadcast_to(_f64_src(w, a), (LANES,)), dtype=np.float64))
+    w.wr(d, np.clip(v, 0, 4294967295.0).astype(U64).astype(U32))
+
+
+@op("ds_bpermute_b32")
+def _ds_bpermute(w, i):
+    # dst[lane] = src[(addr[lane] >> 2) & 63]; a source lane that is disabled by EXEC delivers 0 (ISA manual)
+    d, addr, src = i.args
+    a = (np.asarray(np.broadcast_to(w.rd(addr), (LANES,))).astype(np.int64) + int(i.mods.get("offset", 0))) >> 2 & 63
+    v = np.asarray(np.broadcast_to(w.rd(src), (LANES,)), dtype=U32)
+    em = w.em()
+    w.wr(d, np.where(em[a], v[a], U32(0)))
+
+
+@op("s_lshl_b64")
+def _s_lshl64(w, i):
+    d, a, b = i.args
+    r = (_s64(a, w) << (w.rs(b) & 63)) & 0xFFFFFFFFFFFFFFFF
+    w.wr_smask(d, r)
+    w.scc = 1 if r else 0
+
+
+@op("s_mul_hi_u32")
+def _s_mul_hi(w, i):
+    d, a, b = i.args
+    w.ws(d, (w.rs(a) * w.rs(b)) >> 32)
+
+
+@op("s_min_u32")
+def _s_min(w, i):
+    d, a, b = i.args
+    x, y = w.rs(a), w.rs(b)
+    w.ws(d, min(x, y))
+    w.scc = 1 if x < y else 0
+
+
+@op("s_sub_i32")
+def _s_sub_i32(w, i):
+    d, a, b = i.args
+    w.ws(d, w.rs(a) - w.rs(b))
+
+
+@op("s_subb_u32")
+def _s_subb(w, i):
+    d, a, b = i.args
+    r = w.rs(a) - w.rs(b) - w.scc
+    w.ws(d, r)
+    w.scc = 1 if r < 0 else 0
+
+
+HANDLERS["v_mul_u32_u24"] = _bin(lambda a, b: ((np.asarray(a) & U32(0xFFFFFF)).astype(U64) * (np.asarray(b) & U32(0xFFFFFF)).astype(U64)
+                                                & U64(M32)).astype(U32))

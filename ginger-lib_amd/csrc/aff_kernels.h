@@ -182,6 +182,8 @@ template <class C> struct AffRoundArgs {
                                // applied), T64 in output order -- the backward pass reads them back instead of gathering again
     uint32_t groups;           // lane groups in the grid
     uint32_t bmin;             // minimum batch per lane group (one inversion each)
+    const uint32_t* run_if;    // not null: the launch is the fallback of the assembly kernels (asmgen/g2_rounds.py) and does nothing
+                               // unless their forward kernel raised this flag (an element on the group law's rare branches)
 };
 
 // One lane of a round.  t = global lane-group index, comp = this lane's coefficient, live = lane belongs to a group.
@@ -513,8 +515,24 @@ static __global__ void aff_chunks_kernel(const uint32_t* __restrict__ starts, co
     }
 }
 
+// The inversion between the forward and the backward assembly kernel of a round (asmgen/g2_rounds.py): one wave per T64 tile
+// of running products (tile = wave of the round kernels, slot = lane = lane group * LANES + coefficient), inverted in the
+// tower in place -- one Fp inversion per lane group (F2S / F3S inv: the norm forms of fp2.rs / fp3.rs inverse).
+template <class FS>
+__global__ void __launch_bounds__(256) aff_inv_kernel(void* accs, uint32_t waves, uint32_t n_out, uint32_t B, const uint32_t* flag) {
+    constexpr uint32_t TPW = 64 / FS::LANES;
+    const uint32_t lane = threadIdx.x & 63u, wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (wave >= waves || (uint64_t)wave * TPW * B >= n_out) return;     // that wave of the round kernels had nothing to do
+    if (flag && *flag != 0) return;                                      // the round is redone by aff_round_kernel
+    Fp v = t64_ld_fp(accs, wave, lane);
+    GH_UNROLL for (int i = 0; i < NL; i++) v.l[i] &= LM;                 // the idle lane of a triple wave reads an unwritten slot
+    const Fp r = FS::inv(v);
+    if (lane < TPW * FS::LANES) t64_st_fp(accs, wave, lane, r);
+}
+
 template <class C, class FS, bool R0>
 __global__ void __launch_bounds__(256, FS::WAVES) aff_round_kernel(AffRoundArgs<C> a) {
+    if (a.run_if && *a.run_if == 0) return;
     constexpr uint32_t TPW = 64 / FS::LANES;
     const uint32_t lane = threadIdx.x & 63u, wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const bool live = lane < TPW * FS::LANES;

@@ -6,6 +6,7 @@
 // stream.  They replace hipcc-compiled kernels one for one (same inputs, same outputs: csrc/msm_kernels.h names the
 // counterpart next to each), so every parity test runs through them; GH_ACC_ASM=0 selects the hipcc kernels for A/B runs.
 #include "asm_kernels.h"
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -22,6 +23,7 @@ struct State {
     bool tried = false;
     hipModule_t mod = nullptr;
     hipFunction_t acc_g1[2] = {nullptr, nullptr};   // [0]: p4 (MNT4-753 G1), [1]: p6 (MNT6-753 G1)
+    hipFunction_t aff[2][2][2] = {};                // [tower - 2][fwd][r0]
 };
 State s;
 
@@ -48,6 +50,18 @@ int load_locked() {
             return GH_E_HIP;
         }
     }
+    for (int t = 0; t < 2; t++)
+        for (int fw = 0; fw < 2; fw++)
+            for (int r0 = 0; r0 < 2; r0++) {
+                char nm[64];
+                snprintf(nm, sizeof nm, "gh_asm_aff_f%d_%s_%s", t + 2, fw ? "fwd" : "bwd", r0 ? "r0" : "rn");
+                e = hipModuleGetFunction(&s.aff[t][fw][r0], m, nm);
+                if (e != hipSuccess) {
+                    g_err = std::string("hipModuleGetFunction(") + nm + ") failed: " + hipGetErrorString(e);
+                    hipModuleUnload(m);
+                    return GH_E_HIP;
+                }
+            }
     s.mod = m;
     g.at_shutdown.push_back([] {
         if (s.mod) hipModuleUnload(s.mod);
@@ -77,6 +91,27 @@ int acc_g1_launch(int prime, const void* bases, const uint32_t* sorted, const Ac
     size_t size = sizeof args;
     void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
     HIPCHK(hipModuleLaunchKernel(s.acc_g1[prime == 6 ? 1 : 0], (n_tasks + 255) / 256, 1, 1, 256, 1, 1, 0, st, nullptr, extra));
+    return GH_OK;
+}
+
+bool aff_enabled() {
+    static const bool on = !(getenv("GH_AFF_ASM") && atoi(getenv("GH_AFF_ASM")) == 0);
+    return on;
+}
+
+int aff_launch(int tower, bool fwd, bool r0, const AffArgs& a, uint32_t waves, hipStream_t st) {
+    if (waves == 0 || a.n_out == 0) return GH_OK;
+    if (tower != 2 && tower != 3) { g_err = "internal: aff_launch tower"; return GH_E_BAD_ARG; }
+    // what the kernels' 32-bit index arithmetic assumes (asmgen/g2_rounds.py): element indices times 4 and a wave's list span
+    if ((waves & 3u) || a.n_out >= (1u << 30) || (uint64_t)a.B * 13312u >= (1ull << 32) || a.B == 0) {
+        g_err = "internal: affine round outside the assembly kernels' index range";
+        return GH_E_UNSUPPORTED;
+    }
+    if (int rc = load_locked()) return rc;
+    AffArgs args = a;
+    size_t size = sizeof args;
+    void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+    HIPCHK(hipModuleLaunchKernel(s.aff[tower - 2][fwd ? 1 : 0][r0 ? 1 : 0], waves / 4, 1, 1, 256, 1, 1, 0, st, nullptr, extra));
     return GH_OK;
 }
 

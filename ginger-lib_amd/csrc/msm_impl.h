@@ -816,6 +816,16 @@ struct MsmJob {
         POOLBIG("aff_stage2", stage2, t64_bytes(tiles(max_n1), T64_PT_CHUNKS))
 #undef POOLBIG
         const uint32_t max_waves = (uint32_t)g.num_cus * 4u * (uint32_t)FS::WAVES;
+        const bool aff_asm = C::F::DEG >= 2 && gh_asm::aff_enabled();
+        const uint32_t asm_max_waves = (uint32_t)g.num_cus * 4u * 2u;       // the assembly kernels run two waves per SIMD
+        void* asm_accs = nullptr;
+        uint32_t* asm_flag = nullptr;
+        if (aff_asm) {
+            snprintf(nm, sizeof nm, "aff_accs#%d", slot);
+            if ((rc = pool_get(nm, t64_bytes((size_t)asm_max_waves + 4, T64_FP_CHUNKS), &asm_accs))) return rc;
+            snprintf(nm, sizeof nm, "aff_flag#%d", slot);
+            if ((rc = pool_get(nm, 256, (void**)&asm_flag))) return rc;
+        }
         const Aff<C>* rows = (const Aff<C>*)(merged ? h->d_table : h->d_points);
         for (uint32_t j = 0; j < K; j++) {
             size_t doff = 0;
@@ -836,6 +846,28 @@ struct MsmJob {
                     AffRoundArgs<C> a;
                     a.rows = rows; a.in = in; a.sorted = r == 0 ? sorted : nullptr; a.desc = desc + doff; a.n_out = n_out; a.in_base = T(j, r);
                     a.prefix = prefix; a.out = out; a.stage1 = stage1; a.stage2 = stage2; a.groups = waves * TPW; a.bmin = (uint32_t)env_bmin;
+                    a.run_if = nullptr;
+                    if constexpr (C::F::DEG >= 2) {
+                        if (aff_asm) {
+                            // The assembly kernels (asmgen/g2_rounds.py): forward pass, tower inversion of the lane groups' running
+                            // products, backward pass -- 256 registers, two waves per SIMD, no scratch, no out-of-line product.  A
+                            // round that meets x1 == x2 or an infinity marker raises `flag`; the C++ kernel below then redoes it.
+                            uint32_t aw = (n_out + TPW * (uint32_t)env_bmin - 1) / (TPW * (uint32_t)env_bmin);
+                            if (aw > asm_max_waves) aw = asm_max_waves;
+                            aw = (aw + 3u) & ~3u;
+                            uint32_t Bq = (n_out + aw * TPW - 1) / (aw * TPW);
+                            if (Bq < (uint32_t)env_bmin) Bq = (uint32_t)env_bmin;
+                            gh_asm::AffArgs q;
+                            q.in = r == 0 ? (const void*)rows : in; q.sorted = sorted; q.desc = desc + doff; q.prefix = prefix;
+                            q.stage1 = stage1; q.stage2 = stage2; q.out = out; q.accs = asm_accs; q.flag = asm_flag;
+                            q.n_out = n_out; q.in_base = T(j, r); q.B = Bq; q.pad = 0;
+                            HIPCHK(hipMemsetAsync(asm_flag, 0, 4, st));
+                            if ((rc = gh_asm::aff_launch(C::F::DEG, true, r == 0, q, aw, st))) return rc;
+                            GH_LAUNCH((aff_inv_kernel<FS>), dim3(aw / 4), dim3(256), 0, st, asm_accs, aw, n_out, Bq, (const uint32_t*)asm_flag);
+                            if ((rc = gh_asm::aff_launch(C::F::DEG, false, r == 0, q, aw, st))) return rc;
+                            a.run_if = asm_flag;
+                        }
+                    }
                     if (r == 0) GH_LAUNCH((aff_round_kernel<C, FS, true>), dim3(waves / 4), dim3(256), 0, st, a);
                     else GH_LAUNCH((aff_round_kernel<C, FS, false>), dim3(waves / 4), dim3(256), 0, st, a);
                 }
