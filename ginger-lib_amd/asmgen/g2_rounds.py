@@ -31,6 +31,7 @@ LDS_BYTES = 3 * NL * PARK_STRIDE
 PT_TILE = 13 * 1024          # bytes of one T64 tile of points (13 chunks of 64 x 16 bytes)
 FP_TILE = 7 * 1024           # ... of prefix products
 MARK = 0xFFFFFFFF            # x.l[0] of the infinity marker (aff_kernels.h AFF_MARK)
+FIX_CAP = 16384              # entries of the exception list (control block: 64 bytes + 4 FIX_CAP)
 
 # kernel argument block (bytes)
 ARG_IN, ARG_SORTED, ARG_DESC, ARG_PREFIX, ARG_STAGE1, ARG_STAGE2, ARG_OUT, ARG_ACCS, ARG_FLAG = 0, 8, 16, 24, 32, 40, 48, 56, 64
@@ -236,6 +237,34 @@ def build(name, cfg, fwd, r0, debug=False):
         g.v_add_co_u32(addr_c.lo(), VCC, 12288, addr.lo())
         g.v_addc_co_u32(addr_c.hi(), VCC, 0, addr.hi(), VCC)
 
+    def bad_elements(x1, x2, d, make_d=None):
+        """S_FLAG = the lanes of pairs that need the group law's rare branches -- an infinity marker among the inputs, or x1 == x2
+        (doubling / cancellation, swp.rs:492): any lane of the group sees its marker limb or a zero coefficient of d = x2 - x1 (a
+        superset of d == 0 in the tower).  Uniform over a lane group, and the same in the forward and the backward kernel.  Such an
+        element is treated as a copy here (S_PAIR loses it) and recomputed by aff_fix_kernel from the exception list."""
+        g.v_cmp_eq_u32(S_T0, -1, x1.sub(0))
+        g.v_cmp_eq_u32(S_T1, -1, x2.sub(0))
+        g.s_or_b64(S_T0, S_T0, S_T1)
+        if make_d is not None:                                       # d may take x2's registers
+            make_d()
+        run(f.is_zero_mask(chA, d, S_T1))
+        g.s_or_b64(S_T0, S_T0, S_T1)
+        g.s_and_b64(S_T0, S_T0, S_PAIR)
+        g.s_mov_b64(S_FLAG, 0)
+        g.s_cmp_eq_u64(S_T0, 0)
+        L_NOBAD = g.uniq("nobad")
+        g.s_cbranch_scc1(L_NOBAD)
+        g.v_cndmask_b32(V_T0, 0, 1, S_T0)
+        for i in range(L):                                           # or over the lane group
+            g.ds_bpermute_b32(V(V_T1.idx + i), V_BC[i], V_T0)
+        g.s_waitcnt(lgkmcnt=0)
+        g.v_or_b32(V_T0, V_T1, V_T2)
+        if L == 3:
+            g.v_or_b32(V_T0, V_T0, V_T3)
+        g.v_cmp_ne_u32(S_FLAG, 0, V_T0)
+        g.s_andn2_b64(S_PAIR, S_PAIR, S_FLAG)
+        g.label(L_NOBAD)
+
     # ------------------------------------------------------------ prologue
     g.s_load_dwordx8(S(4, 8), S_KARG, ARG_IN)
     g.s_load_dwordx2(S_STAGE1, S_KARG, ARG_STAGE1)
@@ -333,7 +362,6 @@ def build(name, cfg, fwd, r0, debug=False):
     g.s_mul_i32(S_T1.lo(), S_K, FP_TILE)
     g.s_add_u32(S_ACCS.lo(), S_ACCS.lo(), S_T1.lo())
     g.s_addc_u32(S_ACCS.hi(), S_ACCS.hi(), S_T1.hi())
-    g.s_mov_b64(S_FLAG, 0)
     if r0 and fwd:
         g.v_mul_u32_u24(V_T1, 104, V_COMP)
         g.v_add_co_u32(V_ROWB.lo(), VCC, S_IN.lo(), V_T1)
@@ -368,13 +396,6 @@ def build(name, cfg, fwd, r0, debug=False):
         g.v_mov_b32(V_POFF[0], V_LANE16)
         g.v_add_u32(V_POFF[1], 4096, V_LANE16)
         st_fp_list(ACC, S_ACCS, V_POFF)
-        g.s_cmp_eq_u64(S_FLAG, 0)
-        g.s_cbranch_scc1(L_END + "_noflag")
-        g.v_mov_b32(V_T0, 1)
-        g.v_mov_b32(V_T1, 0)
-        g.s_mov_b64(EXEC, 1)
-        g.global_store_dword(V_T1, V_T0, S_FLAGP)
-        g.label(L_END + "_noflag")
     g.s_endpgm()
 
     # ------------------------------------------------------------ loop head
@@ -448,16 +469,29 @@ def build(name, cfg, fwd, r0, debug=False):
         g.s_waitcnt(vmcnt=0)
 
     if fwd:
-        # rare cases: an infinity marker among the inputs of a pair, or x1 == x2 in this lane's coefficient (a superset of x1 ==
-        # x2 in the tower: doubling / cancellation) -> the round is flagged and redone by the C++ kernel
-        g.v_cmp_eq_u32(S_T0, -1, X1.sub(0))
-        g.v_cmp_eq_u32(S_T1, -1, X2.sub(0))
-        g.s_or_b64(S_T0, S_T0, S_T1)
-        run(f.sub(chA, X2, X1, X2))                                 # d = x2 - x1
-        run(f.is_zero_mask(chA, X2, S_T1))
-        g.s_or_b64(S_T0, S_T0, S_T1)
-        g.s_and_b64(S_T0, S_T0, S_PAIR)
-        g.s_or_b64(S_FLAG, S_FLAG, S_T0)
+        bad_elements(X1, X2, X2, lambda: run(f.sub(chA, X2, X1, X2)))     # d = x2 - x1 (over x2)
+        # exception list: word 1 of the control block counts, the element indices follow from word 16; one lane per group appends
+        L_NOAPP = g.uniq("noappend")
+        g.s_cmp_eq_u64(S_FLAG, 0)
+        g.s_cbranch_scc1(L_NOAPP)
+        g.s_mov_b64(S_T0, EXEC)
+        g.v_cmp_eq_u32(S_T1, 0, V_COMP)
+        g.s_and_b64(S_T1, S_T1, S_FLAG)
+        g.s_and_b64(EXEC, EXEC, S_T1)
+        g.v_mov_b32(V_T0, 1)
+        g.v_mov_b32(V_T1, 0)
+        g.global_atomic_add(V_T2, V_T1, V_T0, S_FLAGP, offset=4, sc0=True)         # sc0: return the count before the add
+        g.s_waitcnt(vmcnt=0)
+        g.s_mov_b32(S_TMP, FIX_CAP)
+        g.v_cmp_gt_u32(S_T1, S_TMP, V_T2)                            # room in the list
+        g.s_andn2_b64(VCC, EXEC, S_T1)                               # lanes without: the whole round falls back (word 0)
+        g.s_and_b64(EXEC, EXEC, S_T1)
+        g.v_lshlrev_b32(V_T2, 2, V_T2)
+        g.global_store_dword(V_T2, V_O, S_FLAGP, offset=64)
+        g.s_mov_b64(EXEC, VCC)
+        g.global_store_dword(V_T1, V_T0, S_FLAGP)
+        g.s_mov_b64(EXEC, S_T0)
+        g.label(L_NOAPP)
         A1, A2, BS, M = E[1], E[2], [E[3], E[4], E[5]], E[7]
         prep_b(X2, BS)
         prep_a(ACC, A1, A2)
@@ -486,6 +520,7 @@ def build(name, cfg, fwd, r0, debug=False):
     park_put(PX2, X2)
     D = E[2]
     run(f.sub(chA, X2, X1, D))
+    bad_elements(X1, X2, D)
     A1, A2, BS = E[3], E[4], [E[5], E[6], E[7]]
     g.s_waitcnt(lgkmcnt=0)                                          # X2 (= E6) is a broadcast target below: parked first
     prep_b(D, BS)

@@ -824,3 +824,15 @@ def _s_subb(w, i):
 
 HANDLERS["v_mul_u32_u24"] = _bin(lambda a, b: ((np.asarray(a) & U32(0xFFFFFF)).astype(U64) * (np.asarray(b) & U32(0xFFFFFF)).astype(U64)
                                                 & U64(M32)).astype(U32))
+
+
+@op("global_atomic_add")
+def _gatomic_add(w, i):
+    d, addr_op, data, saddr = i.args
+    addrs = np.broadcast_to(_vaddr(w, i, addr_op, saddr), (LANES,))
+    em = w.em()
+    vals = np.asarray(np.broadcast_to(w.rd(data), (LANES,)), dtype=U32)
+    for l in np.nonzero(em)[0]:
+        old = int(w.mem.load(int(addrs[l]), 1)[0])
+        w.mem.store(int(addrs[l]), [(old + int(vals[l])) & M32])
+        w.V[w.ridx(d)][l] = old

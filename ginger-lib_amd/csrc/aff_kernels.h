@@ -530,6 +530,75 @@ __global__ void __launch_bounds__(256) aff_inv_kernel(void* accs, uint32_t waves
     if (lane < TPW * FS::LANES) t64_st_fp(accs, wave, lane, r);
 }
 
+// The exceptions of an assembly round (asmgen/g2_rounds.py): pairs that need the group law's rare branches -- P + P (the
+// reference's doubling branch, swp.rs:492), P - P, an infinity marker among the inputs.  The assembly kernels treat such an
+// element as a copy and append its index to the list behind the control block (ctl[0]: the list overflowed, the whole round is
+// redone by aff_round_kernel; ctl[1]: entries; indices from ctl[16]); here every listed element is recomputed by one lane
+// group, with an inversion of its own, and overwrites the copy.  kind: 0 pass-through, 1 generic (a false positive of the
+// list's superset test), 2 doubling, 3 cancellation -- the cases of AffRoundLane::classify.
+constexpr uint32_t AFF_FIX_CAP = 16384;
+template <class C, class FS, bool R0>
+__global__ void __launch_bounds__(256, FS::WAVES) aff_fix_kernel(AffRoundArgs<C> a, const uint32_t* ctl) {
+    constexpr int LANES = FS::LANES;
+    constexpr uint32_t TPW = 64 / LANES;
+    typedef Fp T;
+    if (ctl[0] != 0) return;
+    uint32_t count = ctl[1];
+    if (count > AFF_FIX_CAP) count = AFF_FIX_CAP;
+    if (count == 0) return;
+    const uint32_t lane = threadIdx.x & 63u, wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+    const bool live = lane < TPW * LANES;
+    const uint32_t g = live ? lane / LANES : TPW - 1;
+    const int comp = (int)(lane % LANES);
+    for (uint32_t base = wave * TPW; base < count; base += nwaves * TPW) {      // wave-uniform trip count: the lane-group ops shuffle
+        uint32_t e = base + g;
+        const bool act = live && e < count;
+        if (e >= count) e = count - 1;
+        const uint32_t o = ctl[16 + e];
+        const uint32_t ai = a.desc[o] & 0x7FFFFFFFu;                            // only pairs are listed
+        T x1, y1, x2, y2;
+        if constexpr (R0) {
+            const uint32_t r1 = a.sorted[ai], r2 = a.sorted[ai + 1];
+            const Fp* p1 = reinterpret_cast<const Fp*>(a.rows + (r1 & 0x7FFFFFFFu));
+            const Fp* p2 = reinterpret_cast<const Fp*>(a.rows + (r2 & 0x7FFFFFFFu));
+            x1 = ld_fp(p1 + comp); y1 = ld_fp(p1 + LANES + comp);
+            x2 = ld_fp(p2 + comp); y2 = ld_fp(p2 + LANES + comp);
+            const T n1 = FS::neg(y1), n2 = FS::neg(y2);
+            GH_UNROLL for (int i = 0; i < NL; i++) {
+                y1.l[i] = (r1 >> 31) ? n1.l[i] : y1.l[i];
+                y2.l[i] = (r2 >> 31) ? n2.l[i] : y2.l[i];
+            }
+        } else {
+            const uint32_t i1 = ai - a.in_base, i2 = i1 + 1;
+            x1 = t64_ld_x(a.in, i1 / TPW, (i1 % TPW) * LANES + (uint32_t)comp); y1 = t64_ld_y(a.in, i1 / TPW, (i1 % TPW) * LANES + (uint32_t)comp);
+            x2 = t64_ld_x(a.in, i2 / TPW, (i2 % TPW) * LANES + (uint32_t)comp); y2 = t64_ld_y(a.in, i2 / TPW, (i2 % TPW) * LANES + (uint32_t)comp);
+        }
+        const bool m1 = x1.l[0] == AFF_MARK, m2 = x2.l[0] == AFF_MARK;          // a marker is written to every lane of its group
+        const bool both = !m1 && !m2;
+        const bool eqx = FS::eq(x1, x2), eqy = FS::eq(y1, y2), y0 = FS::is_zero(y1);
+        const int kind = !both ? 0 : (!eqx ? 1 : ((eqy && !y0) ? 2 : 3));
+        const T dx = FS::sub(x2, x1), y2x = FS::dbl(y1), one = FS::one();
+        T d, num = FS::sub(y2, y1);
+        GH_UNROLL for (int i = 0; i < NL; i++) d.l[i] = kind == 1 ? dx.l[i] : (kind == 2 ? y2x.l[i] : one.l[i]);
+        const T dinv = FS::inv(d);
+        {
+            const T xx = FS::sqr(x1);
+            const T n2 = FS::add(FS::add(FS::dbl(xx), xx), CurveA<C, FS>::get(comp));      // 3 x1^2 + a
+            GH_UNROLL for (int i = 0; i < NL; i++) num.l[i] = kind == 2 ? n2.l[i] : num.l[i];
+        }
+        const T lam = FS::mul(num, dinv);
+        T x3 = FS::sub(FS::sub(FS::sqr(lam), x1), x2);
+        T y3 = FS::sub(FS::mul(lam, FS::sub(x1, x3)), y1);
+        const bool take1 = m2, take2 = m1 && !m2;                               // P + marker -> P, marker + Q -> Q (marker + marker: P, a marker)
+        GH_UNROLL for (int i = 0; i < NL; i++) {
+            x3.l[i] = take1 ? x1.l[i] : (take2 ? x2.l[i] : (kind == 3 ? 0u : x3.l[i]));
+            y3.l[i] = take1 ? y1.l[i] : (take2 ? y2.l[i] : (kind == 3 ? 0u : y3.l[i]));
+        }
+        if (kind == 3) x3.l[0] = AFF_MARK;
+        if (act) t64_st_xy(a.out, o / TPW, (o % TPW) * LANES + (uint32_t)comp, x3, y3);
+    }
+}
+
 template <class C, class FS, bool R0>
 __global__ void __launch_bounds__(256, FS::WAVES) aff_round_kernel(AffRoundArgs<C> a) {
     if (a.run_if && *a.run_if == 0) return;

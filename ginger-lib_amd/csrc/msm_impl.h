@@ -824,7 +824,7 @@ struct MsmJob {
             snprintf(nm, sizeof nm, "aff_accs#%d", slot);
             if ((rc = pool_get(nm, t64_bytes((size_t)asm_max_waves + 4, T64_FP_CHUNKS), &asm_accs))) return rc;
             snprintf(nm, sizeof nm, "aff_flag#%d", slot);
-            if ((rc = pool_get(nm, 256, (void**)&asm_flag))) return rc;
+            if ((rc = pool_get(nm, 64 + 4 * (size_t)AFF_FIX_CAP, (void**)&asm_flag))) return rc;   // control block + exception list
         }
         const Aff<C>* rows = (const Aff<C>*)(merged ? h->d_table : h->d_points);
         for (uint32_t j = 0; j < K; j++) {
@@ -850,8 +850,8 @@ struct MsmJob {
                     if constexpr (C::F::DEG >= 2) {
                         if (aff_asm) {
                             // The assembly kernels (asmgen/g2_rounds.py): forward pass, tower inversion of the lane groups' running
-                            // products, backward pass -- 256 registers, two waves per SIMD, no scratch, no out-of-line product.  A
-                            // round that meets x1 == x2 or an infinity marker raises `flag`; the C++ kernel below then redoes it.
+                            // products, backward pass -- 256 registers, two waves per SIMD, no scratch, no out-of-line product.
+                            // Elements on the group law's rare branches go through an exception list (aff_fix_kernel).
                             uint32_t aw = (n_out + TPW * (uint32_t)env_bmin - 1) / (TPW * (uint32_t)env_bmin);
                             if (aw > asm_max_waves) aw = asm_max_waves;
                             aw = (aw + 3u) & ~3u;
@@ -861,11 +861,23 @@ struct MsmJob {
                             q.in = r == 0 ? (const void*)rows : in; q.sorted = sorted; q.desc = desc + doff; q.prefix = prefix;
                             q.stage1 = stage1; q.stage2 = stage2; q.out = out; q.accs = asm_accs; q.flag = asm_flag;
                             q.n_out = n_out; q.in_base = T(j, r); q.B = Bq; q.pad = 0;
-                            HIPCHK(hipMemsetAsync(asm_flag, 0, 4, st));
+                            HIPCHK(hipMemsetAsync(asm_flag, 0, 16, st));
                             if ((rc = gh_asm::aff_launch(C::F::DEG, true, r == 0, q, aw, st))) return rc;
                             GH_LAUNCH((aff_inv_kernel<FS>), dim3(aw / 4), dim3(256), 0, st, asm_accs, aw, n_out, Bq, (const uint32_t*)asm_flag);
                             if ((rc = gh_asm::aff_launch(C::F::DEG, false, r == 0, q, aw, st))) return rc;
+                            // the listed exceptions (doubling, cancellation, markers), one lane group each; then, only if the list
+                            // overflowed, the whole round once more on the C++ kernel
+                            if (r == 0) GH_LAUNCH((aff_fix_kernel<C, FS, true>), dim3(16), dim3(256), 0, st, a, (const uint32_t*)asm_flag);
+                            else GH_LAUNCH((aff_fix_kernel<C, FS, false>), dim3(16), dim3(256), 0, st, a, (const uint32_t*)asm_flag);
                             a.run_if = asm_flag;
+                            static const bool aff_debug = getenv("GH_AFF_DEBUG") != nullptr;
+                            if (aff_debug) {      // how many elements of the round went through the exception list / whether it overflowed
+                                uint32_t fw[4] = {0, 0, 0, 0};
+                                HIPCHK(hipStreamSynchronize(st));
+                                HIPCHK(hipMemcpy(fw, asm_flag, 16, hipMemcpyDeviceToHost));
+                                fprintf(stderr, "[gh aff] chunk %u round %d n_out %u waves %u B %u in_base %u redo %u exceptions %u\n", j, r, n_out, aw, Bq,
+                                        q.in_base, fw[0], fw[1]);
+                            }
                         }
                     }
                     if (r == 0) GH_LAUNCH((aff_round_kernel<C, FS, true>), dim3(waves / 4), dim3(256), 0, st, a);

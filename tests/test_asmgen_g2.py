@@ -86,7 +86,7 @@ def sim_runner(g, bufs, scalars, waves):
         bufs[k][...] = mem.get(k).reshape(bufs[k].shape)
 
 
-def _run_round(cname, r0, n_out, B, waves, desc, rows=None, sorted_l=None, in_list=None, in_base=0, expect_flag=False,
+def _run_round(cname, r0, n_out, B, waves, desc, rows=None, sorted_l=None, in_list=None, in_base=0, expect_bad=(),
                runner=sim_runner):
     C = pyref.CURVES[cname]
     p, L = C.F.p, C.deg
@@ -97,7 +97,7 @@ def _run_round(cname, r0, n_out, B, waves, desc, rows=None, sorted_l=None, in_li
     prefix, stage1, stage2, out = T64(tiles, 7), T64(tiles, 13), T64(tiles, 13), T64(tiles, 13)
     accs = T64(waves + 1, 7)
     bufs = {"prefix": prefix.a, "stage1": stage1.a, "stage2": stage2.a, "out": out.a, "accs": accs.a,
-            "flag": np.zeros(64, dtype=np.uint32), "desc": np.array(desc, dtype=np.uint32),
+            "flag": np.zeros(16 + G2.FIX_CAP, dtype=np.uint32), "desc": np.array(desc, dtype=np.uint32),
             "sorted": np.array(sorted_l if sorted_l is not None else [0], dtype=np.uint32)}
     if r0:
         enc = np.zeros((len(rows), 2 * L, 26), dtype=np.uint32)
@@ -109,8 +109,9 @@ def _run_round(cname, r0, n_out, B, waves, desc, rows=None, sorted_l=None, in_li
     else:
         bufs["in"] = in_list.a
     runner(gf, bufs, (n_out, in_base, B), waves)
-    flag = int(bufs["flag"][0])
-    assert (flag != 0) == expect_flag
+    # the control block: word 0 = the whole round falls back (list overflow), word 1 = entries of the exception list (from word 16)
+    ctl = bufs["flag"]
+    assert int(ctl[0]) == 0 and int(ctl[1]) == len(expect_bad) and sorted(int(x) for x in ctl[16:16 + int(ctl[1])]) == sorted(expect_bad)
     # the inversion between the kernels (aff_inv_kernel on the device): per lane group, in the tower
     ri = pow(R, -1, p)
     for wv in range(waves):
@@ -118,11 +119,12 @@ def _run_round(cname, r0, n_out, B, waves, desc, rows=None, sorted_l=None, in_li
             continue
         for gidx in range(TPW):
             v = tuple(accs.get_fp(wv, gidx * L + j) * ri % p for j in range(L))
-            assert not C.E.is_zero(v) or expect_flag
-            iv = C.E.inv(v) if not C.E.is_zero(v) else v
+            assert not C.E.is_zero(v)                            # exceptions stay out of the running product
+            iv = C.E.inv(v)
             for j in range(L):
                 accs.put_fp(wv, gidx * L + j, iv[j] * R % p)
     runner(gb, bufs, (n_out, in_base, B), waves)
+    assert int(ctl[1]) == len(expect_bad)
     return out, stage1, stage2, gf, gb
 
 
@@ -210,16 +212,35 @@ def test_g2_round_kernels_in_the_simulator(cname):
         assert _tower_pt(out1, wv * B2 + k, g, L, p) == exp2[o], o
 
 
-@pytest.mark.parametrize("cname", ["mnt4753_g2"])
-def test_g2_round_kernel_flags_the_rare_cases(cname):
+@pytest.mark.parametrize("cname", ["mnt4753_g2", "mnt6753_g2"])
+def test_g2_round_kernels_list_the_rare_cases(cname):
+    """P + P (the reference's doubling branch, swp.rs:492), P - P and an infinity marker among a pair's inputs do not enter the
+    shared inversion: the forward kernel appends such elements to the exception list (aff_fix_kernel recomputes them on the
+    device), both kernels treat them as copies, and every other element of the round is still the group law's sum."""
     C = pyref.CURVES[cname]
-    L = C.deg
+    p, L = C.F.p, C.deg
     TPW = 64 // L
-    pts = [C.G, C.add(C.G, C.G), C.mul(5, C.G)]
-    # P + P (the reference's doubling branch, swp.rs:492) in element 1: the forward kernel raises the flag, the backward one leaves
-    desc = [0 | 0x80000000, 2 | 0x80000000, 4]
-    sorted_l = [0, 1, 2, 2, 1, 0]
-    _run_round(cname, True, 3, 1, 1, desc, rows=pts, sorted_l=sorted_l, expect_flag=True)
-    # P - P as well (same x)
-    sorted_l = [0, 1, 2, 2 | 0x80000000, 1, 0]
-    _run_round(cname, True, 3, 1, 1, desc, rows=pts, sorted_l=sorted_l, expect_flag=True)
+    pts = [C.G, C.add(C.G, C.G), C.mul(5, C.G), C.mul(7, C.G)]
+    desc = [0 | 0x80000000, 2 | 0x80000000, 4 | 0x80000000, 6, 7 | 0x80000000]
+    sorted_l = [0, 1, 2, 2, 3, 3 | 0x80000000, 1, 0, 2, 0]            # G + 2G | 5G + 5G | 7G - 7G | copy 2G | G + 5G
+    out, _, _, _, _ = _run_round(cname, True, 5, 1, 1, desc, rows=pts, sorted_l=sorted_l, expect_bad=(1, 2))
+    assert _tower_pt(out, 0, 0, L, p) == C.mul(3, C.G)
+    assert _tower_pt(out, 0, 3, L, p) == pts[1]
+    assert _tower_pt(out, 0, 4, L, p) == C.mul(6, C.G)
+    assert _tower_pt(out, 0, 1, L, p) == pts[2]                       # exceptions leave as copies of their first input
+    # a later round with an infinity marker (x.l[0] = 0xFFFFFFFF) among its inputs
+    lst = T64(2, 13)
+    vals = [C.G, None, C.mul(5, C.G), C.mul(7, C.G), C.mul(9, C.G), None]
+    for o, v in enumerate(vals):
+        for j in range(L):
+            if v is None:
+                lst.put_pt(0, o * L + j, 0, 0)
+                lst.words(0, o * L + j)      # (view)
+                lst.a[0, 0, o * L + j, 0] = 0xFFFFFFFF
+            else:
+                lst.put_pt(0, o * L + j, v[0][j] * R % p, v[1][j] * R % p)
+    desc = [0 | 0x80000000, 2 | 0x80000000, 4, 5]                    # G + marker | 5G + 7G | copy 9G | copy marker
+    out, _, _, _, _ = _run_round(cname, False, 4, 1, 1, desc, in_list=lst, expect_bad=(0,))
+    assert _tower_pt(out, 0, 1, L, p) == C.mul(12, C.G)
+    assert _tower_pt(out, 0, 2, L, p) == C.mul(9, C.G)
+    assert int(out.a[0, 0, 3 * L, 0]) == 0xFFFFFFFF                   # a copied marker stays a marker
