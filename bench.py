@@ -113,7 +113,6 @@ def main():
             return distmod.CDist(gl, rank, world, transport="callback", allgather=distmod.gloo_allgather_bytes(dist))
         if backend == "rccl":
             from torch.distributed.distributed_c10d import _get_default_store
-            import signal
             import torch
             # Step 1, local and collective-free: can THIS rank load and bind librccl?  The ranks agree on the answer over gloo
             # BEFORE anyone enters ncclCommInitRank -- a rank that failed alone would otherwise leave the others blocked in it.
@@ -124,11 +123,17 @@ def main():
             if not err:
                 # Step 2, collective, under a watchdog: a communicator that does not come up within two minutes ends the job
                 # with a non-zero status instead of hanging it.
-                def _watchdog(signum, frame):
+                # (A timer THREAD: the main thread sits inside a ctypes call -- ncclCommInitRank or the probe all-gather -- where
+                #  CPython runs no signal handler; ctypes releases the GIL, so the timer fires and ends the process.  ADVICE r3.)
+                import threading
+
+                def _watchdog():
                     sys.stderr.write("bench.py rank %d: RCCL communicator did not come up within 120 s\n" % rank)
+                    sys.stderr.flush()
                     os._exit(3)
-                signal.signal(signal.SIGALRM, _watchdog)
-                signal.alarm(120)
+                wd = threading.Timer(120.0, _watchdog)
+                wd.daemon = True
+                wd.start()
                 try:
                     cdist = distmod.CDist(gl, rank, world, transport="rccl", store=_get_default_store())
                     ident = np.zeros(36 * pyref.CURVES[args.curve].deg, dtype=np.uint64)
@@ -136,7 +141,7 @@ def main():
                     cdist.allgather_fold(args.curve, ident)
                 except Exception as e:      # noqa: reported below
                     err = "%s: %s" % (type(e).__name__, e)
-                signal.alarm(0)
+                wd.cancel()
                 flag = torch.tensor([0 if err else 1])
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
                 if int(flag.item()) == 0 and not err:

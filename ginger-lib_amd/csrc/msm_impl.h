@@ -817,7 +817,10 @@ struct MsmJob {
 #undef POOLBIG
         const uint32_t max_waves = (uint32_t)g.num_cus * 4u * (uint32_t)FS::WAVES;
         const bool aff_asm = C::F::DEG >= 2 && gh_asm::aff_enabled();
-        const uint32_t asm_max_waves = (uint32_t)g.num_cus * 4u * 2u;       // the assembly kernels run two waves per SIMD
+        // the assembly kernels run two waves per SIMD; GH_AFF_WAVES_MUL x that many waves are launched so that the blocks (equal
+        // work each) are dealt out dynamically instead of as one exact fill of the chip
+        static const int env_wmul = getenv("GH_AFF_WAVES_MUL") ? atoi(getenv("GH_AFF_WAVES_MUL")) : 1;
+        const uint32_t asm_max_waves = (uint32_t)g.num_cus * 4u * 2u * (uint32_t)(env_wmul > 0 && env_wmul <= 16 ? env_wmul : 1);
         void* asm_accs = nullptr;
         uint32_t* asm_flag = nullptr;
         if (aff_asm) {
