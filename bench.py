@@ -54,6 +54,8 @@ def main():
     ap.add_argument("--no-ntt", action="store_true")
     ap.add_argument("--no-2p24", action="store_true", help="skip the extra 2^24-pair object (BASELINE config 3's second size)")
     ap.add_argument("--no-g2", action="store_true", help="skip the extra G2 objects (MNT4-753 G2 2^20, MNT6-753 G2 2^19)")
+    ap.add_argument("--no-prover", action="store_true", help="skip the `prover` object (BASELINE config 5: create_proof at 2^20 - 3 constraints)")
+    ap.add_argument("--prover-log-n", type=int, default=20, help="domain size of the prover object's Benchmark circuit (constraints = 2^k - 3)")
     ap.add_argument("--curve", default="mnt4753_g1", choices=["mnt4753_g1", "mnt4753_g2", "mnt6753_g1", "mnt6753_g2"])
     ap.add_argument("--total-log-n", type=int, default=0,
                     help="strong scaling (BASELINE config 4): 2^total-log-n pairs in all, 2^total-log-n / N per GPU; overrides --log-n")
@@ -308,15 +310,27 @@ def main():
         dist.all_reduce(f, op=dist.ReduceOp.MIN)
         cf_ok = bool(int(f.item()))
     fpmul_rate = madds * per_add / (acc_avg_ms * 1e-3)
+    # measured on this box, in this run: the product peak and what the code object says about the three hot kernels
+    peak_now, hot_kernels = None, None
+    if rank == 0:
+        try:
+            peak_now = gl.measure_fpmul_peak()
+            hot_kernels = {k: gl.kernel_resources(k) for k in ("g1_acc_p4", "g2_f2_bwd_r0", "g2_f3_bwd_r0")}
+            hot_kernels["note"] = ("generated gfx950 assembly (ginger-lib_amd/asmgen): G1 XYZZ bucket update, backward kernels of the Fq2 / Fq3 affine "
+                                   "rounds; scratch_bytes_per_lane / registers / lds_bytes as hipFuncGetAttribute reports them for the loaded code object")
+        except gl.GingerHipError as e:
+            hot_kernels = {"error": str(e)}
 
     # HBM traffic per launch of the dominant kernels: PMC counters collected with rocprofv3 in separate
     # passes on this same command (profiles/r01_pmc_traffic.json); null if that file is absent or the
     # workload differs from the profiled one (2^20 pairs / 2^24 points).
     traffic_acc = traffic_ntt = None
     traffic_g2 = {}
-    traffic_src = "profiles/r03_pmc_traffic.json"
+    traffic_src = "profiles/r04_pmc_traffic.json"
+    traffic_when = None
     try:
         tr = json.load(open(os.path.join(ROOT, traffic_src)))
+        traffic_when = tr.get("measured")
         if tr.get("kernels_sha256") == kernels_sha():          # counters go stale when the kernels change: then null
             ent = tr.get("%s_2p%d" % (curve, n.bit_length() - 1))
             if ent and ent["window_bits"] == tm_last["window_bits"] and ent["bucket_sums"] == bucket_mode:
@@ -359,12 +373,16 @@ def main():
                             "Python integers (tests/support.py chain_msm_closed_form): an answer no MSM code path produced",
         "roofline": {"kernel": "%s (bucket accumulation of the %s MSM)" % ("msm_accumulate_xyzz_kernel" if xyzz else "msm_accumulate_kernel / aff_round_kernel", curve), "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_acc,
-                     "traffic_note": "FETCH_SIZE + WRITE_SIZE bytes of the accumulation launches of one MSM from %s (separate rocprofv3 --pmc passes), null when that file was measured on other kernel sources (sha256 of ginger-lib_amd/csrc) or another workload" % traffic_src,
+                     "traffic_note": "FETCH_SIZE + WRITE_SIZE bytes of the accumulation launches of one MSM from %s (separate rocprofv3 --pmc passes), null when that file was measured on other kernel sources (sha256 of ginger-lib_amd/csrc) or another workload; measured by the builder: %s" % (traffic_src, traffic_when or "box and date unknown"),
                      "avg_launch_ms": acc_avg_ms, "algorithmic_bytes_per_launch": alg_bytes,
                      "note": "integer-VALU bound by construction (SURVEY 8d): see valu"},
         "valu": {"achieved_fpmul_per_s": fpmul_rate, "peak_fpmul_per_s": FPMUL_PEAK_PER_S, "frac": fpmul_rate / FPMUL_PEAK_PER_S,
+                 "peak_fpmul_per_s_measured_now": peak_now, "frac_of_measured_peak": (fpmul_rate / peak_now) if peak_now else None,
                  "fp_products_per_addition": per_add,
-                 "note": "peak = measured rr29 Montgomery-product microbenchmark (profiles/r01_microbench_valu_rates.txt)"},
+                 "note": "peak = the round-1 rr29 Montgomery-product microbenchmark (profiles/r01_microbench_valu_rates.txt); "
+                         "peak_fpmul_per_s_measured_now = the same kind of loop (two interleaved products per lane, asmgen/microbench.py) "
+                         "run by the library on THIS card in this process (gh_measure_fpmul_peak)"},
+        "hot_kernels": hot_kernels,
         "phases_ms": phases,
         "phases_alone_ms": phases_alone,
         "phases_note": "per-MSM device phases by HIP events on their streams; with the pipelined batch the phases of neighbouring "
@@ -629,6 +647,82 @@ def main():
                                           "gpu_matches_oracle_on_sample": bool((got == ref).all())}
     rb.free()
     ds.free()
+    # ---- BASELINE config 5: create_proof of the `Benchmark` circuit (examples/snark-scalability/constraints.rs:20-92) with
+    #      2^20 - 3 constraints over MNT4-753, from a key GENERATED on the device (groth16.generate_parameters mirrors
+    #      generator.rs:146-335: gh_lagrange_coefficients + gh_fixed_base_msm_affine), serialised as Parameters::write does, parsed
+    #      and made resident (gh_bases_upload_wire + shift tables); the timed part is prover.rs:201-346 from the host's limb arrays
+    #      on: rows over PCIe, witness map, into_repr, four G1 MSMs as one batch and one G2 MSM, host fold.  A, B, C are checked
+    #      against the Groth16 equations evaluated in the exponent from the toxic waste (no MSM / FFT code path involved).
+    if not args.no_prover and rank == 0 and world == 1 and curve == "mnt4753_g1" and not args.window:
+        try:
+            gl.dev_trim()
+            import importlib
+            groth16 = importlib.import_module("ginger_lib_amd.groth16")
+            def wire(Cc, P):          # GroupAffine::write (short_weierstrass_projective.rs:185-192) of a Python point
+                xs, ys = (tuple([0] * Cc.deg), tuple([1] + [0] * (Cc.deg - 1))) if P is None else P
+                return b"".join(int(v).to_bytes(96, "little") for v in tuple(xs) + tuple(ys)) + (b"\x01" if P is None else b"\x00")
+            pairing = "mnt4753"
+            C1, C2 = pyref.CURVES[pairing + "_g1"], pyref.CURVES[pairing + "_g2"]
+            rr = C1.order
+            n_con = (1 << args.prover_log_n) - 3
+            prng = pyref.Rng(2026)
+            alpha, beta, gamma, delta, tau, r_, s_ = (prng.field_elem(rr) for _ in range(7))
+            g1, g2 = C1.mul(prng.next_u64() | 1, C1.G), C2.mul(prng.next_u64() | 1, C2.G)
+            t1 = time.perf_counter()
+            lcs = groth16.benchmark_circuit_lcs(n_con)
+            blob, info = groth16.generate_parameters(gl, pairing, lcs, alpha, beta, gamma, delta, tau, S.proj_array(C1, g1), S.proj_array(C2, g2))
+            gen_s = time.perf_counter() - t1
+            del lcs
+            t1 = time.perf_counter()
+            key = groth16.ResidentProvingKey.from_parameters(gl, pairing, blob, 3)
+            load_s = time.perf_counter() - t1
+            blob_mb = len(blob) / 1048576.0
+            del blob
+            try:
+                t1 = time.perf_counter()
+                rows = groth16.benchmark_circuit_rows(pairing, n_con)
+                prep = key.prepare_rows(rows, 0, 0, 0)
+                host_rows_s = time.perf_counter() - t1
+                key.prove_prepared(prep, r_, s_)                       # untimed: pipeline slots and pools are allocated on first use
+                KP, tms, proof = 3, [], None
+                for _ in range(KP):
+                    tm = {}
+                    t1 = time.perf_counter()
+                    proof = key.prove_prepared(prep, r_, s_, timing=tm)
+                    tm["proof_ms"] = (time.perf_counter() - t1) * 1e3
+                    tms.append(tm)
+            finally:
+                key.free()
+                gl.dev_trim()
+            a_, b_, c_, l_, zt_ = info["qap"]
+            asg = rows[1]
+            sa = sum(x * y for x, y in zip(asg, a_)) % rr
+            sb = sum(x * y for x, y in zip(asg, b_)) % rr
+            sc = sum(x * y for x, y in zip(asg, c_)) % rr
+            di = pow(delta, -1, rr)
+            A_s = (alpha + sa + r_ * delta) % rr
+            B_s = (beta + sb + s_ * delta) % rr
+            H_s = (sa * sb - sc) * di % rr                           # h(t) Z(t) / delta with d1 = d2 = d3 = 0 (QAP divisibility)
+            C_s = (sum(asg[i] * l_[i] for i in range(3, len(asg))) + H_s + s_ * A_s + r_ * B_s - r_ * s_ * delta) % rr
+            exp = wire(C1, C1.mul(A_s, g1)) + wire(C2, C2.mul(B_s, g2)) + wire(C1, C1.mul(C_s, g1))
+            mean = lambda k: float(np.mean([t[k] for t in tms]))
+            out["prover"] = {"workload": "Groth16 create_proof, MNT4-753, `Benchmark` circuit with 2^%d - 3 constraints (BASELINE config 5), key generated on the "
+                                         "device, resident with shift tables" % args.prover_log_n,
+                             "proofs_timed": KP, "proof_ms": mean("proof_ms"), "rows_upload_ms": mean("rows_upload_ms"),
+                             "witness_map_ms": mean("witness_map_ms"), "msm_stage_ms": mean("msm_stage_ms"),
+                             "device_ms": mean("witness_map_ms") + mean("msm_stage_ms"),
+                             "stages": "prover.rs:201-346 from the host's limb arrays: rows over PCIe (3 x 2^%d x 96 B), gh_witness_map_dev + into_repr, "
+                                       "4 G1 MSMs as one pipelined batch + 1 G2 MSM + host fold; the Python-integer row evaluation (host_rows_s) is "
+                                       "outside, as the reference's constraint synthesis is" % args.prover_log_n,
+                             "key_generate_s": gen_s, "key_generate_fixed_base_s": info["fixed_base"]["fixed_base_s"],
+                             "key_bytes_mb": blob_mb, "key_load_s": load_s, "host_rows_s": host_rows_s,
+                             "closed_form_ok": bool(proof == exp),
+                             "closed_form_note": "Proof::write bytes equal (alpha + sum a_i(t) x_i + r delta) g1, (beta + sum b_i(t) x_i + s delta) g2, "
+                                                 "(sum_aux x_i l_i + h(t) Z(t) / delta + s A + r B - r s delta) g1 computed from the toxic waste with Python integers"}
+            if not out["prover"]["closed_form_ok"]:
+                out["error"] = "prover: proof differs from the Groth16 equations in the exponent"
+        except gl.GingerHipError as e:
+            out["prover"] = {"error": str(e)}
     if rank == 0:
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if world > 1:

@@ -35,7 +35,7 @@ ABI_SYMBOLS = [
     "gh_bases_key_id", "gh_test_hooks",
     "gh_msm_set_window", "gh_msm_set_affine", "gh_msm_get_window", "gh_msm_last_timing", "gh_msm_batch_timing",
     "gh_domain_supported", "gh_fft", "gh_fft_dev", "gh_vec_mul_dev", "gh_vec_sub_dev", "gh_vec_scale_dev",
-    "gh_vec_mul", "gh_vec_scale", "gh_fft_last_kernel_ms", "gh_witness_map", "gh_witness_map_dev",
+    "gh_vec_mul", "gh_vec_scale", "gh_fft_last_kernel_ms", "gh_measure_fpmul_peak", "gh_kernel_resources", "gh_witness_map", "gh_witness_map_dev",
     "gh_sap_witness_map", "gh_sap_witness_map_dev", "gh_batch_inverse", "gh_batch_inverse_dev",
     "gh_lagrange_coefficients", "gh_lagrange_coefficients_dev",
     "gh_dev_alloc", "gh_dev_free", "gh_dev_upload", "gh_dev_download", "gh_dev_sync", "gh_dev_trim",
@@ -101,6 +101,8 @@ def load_library():
     lib.gh_key_cache_stats.argtypes = [ctypes.POINTER(KeyCacheStats)]
     lib.gh_bases_content_hash.argtypes = [ci, vp, vp, sz, ctypes.POINTER(ctypes.c_uint64)]
     lib.gh_bases_content_hash.restype = ctypes.c_uint64
+    lib.gh_measure_fpmul_peak.argtypes = [ctypes.POINTER(ctypes.c_double)]
+    lib.gh_kernel_resources.argtypes = [ctypes.c_char_p, ctypes.POINTER(u32), ctypes.POINTER(u32), ctypes.POINTER(u32)]
     lib.gh_bases_key_id.argtypes = [ci, vp, vp, sz, ctypes.POINTER(ctypes.c_uint64)]
     lib.gh_test_hooks.argtypes = [ci]
     lib.gh_msm_set_window.argtypes = [ci]
@@ -244,6 +246,20 @@ def bases_content_hash(curve, bases, infinity=None):
     hi = ctypes.c_uint64(0)
     lo = load_library().gh_bases_content_hash(CURVES[curve], _ptr(bases), _ptr(inf) if inf is not None else None, bases.size // (24 * deg), ctypes.byref(hi))
     return int(lo), int(hi.value)
+
+
+def measure_fpmul_peak():
+    """753-bit Montgomery products per second of this card, measured now (gh_measure_fpmul_peak)"""
+    v = ctypes.c_double(0)
+    _check(load_library().gh_measure_fpmul_peak(ctypes.byref(v)))
+    return float(v.value)
+
+
+def kernel_resources(which):
+    """scratch bytes per lane, registers and LDS bytes of a generated kernel, from the loaded code object"""
+    a, b, c = ctypes.c_uint32(0), ctypes.c_uint32(0), ctypes.c_uint32(0)
+    _check(load_library().gh_kernel_resources(which.encode(), ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+    return {"scratch_bytes_per_lane": int(a.value), "registers": int(b.value), "lds_bytes": int(c.value)}
 
 
 def bases_key_id(curve, bases, infinity=None):

@@ -10,7 +10,7 @@ import os
 import subprocess
 import sys
 
-from . import g1_xyzz, g2_rounds
+from . import g1_xyzz, g2_rounds, microbench
 from .isa import module_text
 
 LLVM = os.environ.get("GH_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
@@ -32,6 +32,7 @@ def programs():
         for fwd in (True, False):
             for r0 in (True, False):
                 progs.append(g2_rounds.build("gh_asm_aff_%s_%s_%s" % (tag, "fwd" if fwd else "bwd", "r0" if r0 else "rn"), cfg, fwd, r0))
+    progs.append(microbench.build("gh_asm_mb_mulpair", P4))
     if os.environ.get("GH_ASM_DEBUG"):          # stage markers for tools/asm_g2_check.py (not shipped)
         progs.append(g2_rounds.build("gh_asm_aff_f2_bwd_r0_dbg", c2, False, True, debug=True))
     if os.environ.get("GH_ASM_VARIANTS"):      # A/B variants of the gather for tools/asm_mb/acc_run.hip (not shipped)

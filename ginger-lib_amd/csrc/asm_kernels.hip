@@ -24,6 +24,7 @@ struct State {
     hipModule_t mod = nullptr;
     hipFunction_t acc_g1[2] = {nullptr, nullptr};   // [0]: p4 (MNT4-753 G1), [1]: p6 (MNT6-753 G1)
     hipFunction_t aff[2][2][2] = {};                // [tower - 2][fwd][r0]
+    hipFunction_t mb_mulpair = nullptr;
 };
 State s;
 
@@ -62,6 +63,12 @@ int load_locked() {
                     return GH_E_HIP;
                 }
             }
+    e = hipModuleGetFunction(&s.mb_mulpair, m, "gh_asm_mb_mulpair");
+    if (e != hipSuccess) {
+        g_err = std::string("hipModuleGetFunction(gh_asm_mb_mulpair) failed: ") + hipGetErrorString(e);
+        hipModuleUnload(m);
+        return GH_E_HIP;
+    }
     s.mod = m;
     g.at_shutdown.push_back([] {
         if (s.mod) hipModuleUnload(s.mod);
@@ -112,6 +119,54 @@ int aff_launch(int tower, bool fwd, bool r0, const AffArgs& a, uint32_t waves, h
     size_t size = sizeof args;
     void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
     HIPCHK(hipModuleLaunchKernel(s.aff[tower - 2][fwd ? 1 : 0][r0 ? 1 : 0], waves / 4, 1, 1, 256, 1, 1, 0, st, nullptr, extra));
+    return GH_OK;
+}
+
+int measure_fpmul_peak(double* products_per_s, hipStream_t st) {
+    if (int rc = load_locked()) return rc;
+    const uint32_t iters = 200, blocks = (uint32_t)g.num_cus * 2u;      // two blocks of 4 waves per CU = two waves per SIMD
+    struct { uint32_t iters, pad; } args = {iters, 0};
+    size_t size = sizeof args;
+    void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    float best = 0;
+    for (int rep = 0; rep < 4; rep++) {        // the first launch pays the code upload
+        HIPCHK(hipEventRecord(e0, st));
+        HIPCHK(hipModuleLaunchKernel(s.mb_mulpair, blocks, 1, 1, 256, 1, 1, 0, st, nullptr, extra));
+        HIPCHK(hipEventRecord(e1, st));
+        HIPCHK(hipEventSynchronize(e1));
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+        if (rep > 0 && (best == 0 || ms < best)) best = ms;
+    }
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    if (products_per_s) *products_per_s = best > 0 ? (double)blocks * 256.0 * 2.0 * iters / (best * 1e-3) : 0.0;
+    return GH_OK;
+}
+
+int kernel_resources(const char* which, uint32_t* scratch, uint32_t* vgprs, uint32_t* lds) {
+    if (int rc = load_locked()) return rc;
+    hipFunction_t f = nullptr;
+    const std::string w = which ? which : "";
+    if (w == "g1_acc_p4") f = s.acc_g1[0];
+    else if (w == "g1_acc_p6") f = s.acc_g1[1];
+    else if (w == "g2_f2_fwd_r0") f = s.aff[0][1][1];
+    else if (w == "g2_f2_bwd_r0") f = s.aff[0][0][1];
+    else if (w == "g2_f2_bwd_rn") f = s.aff[0][0][0];
+    else if (w == "g2_f3_fwd_r0") f = s.aff[1][1][1];
+    else if (w == "g2_f3_bwd_r0") f = s.aff[1][0][1];
+    else if (w == "g2_f3_bwd_rn") f = s.aff[1][0][0];
+    else { g_err = "unknown kernel name"; return GH_E_BAD_ARG; }
+    int v = 0;
+    HIPCHK(hipFuncGetAttribute(&v, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, f));
+    if (scratch) *scratch = (uint32_t)v;
+    HIPCHK(hipFuncGetAttribute(&v, HIP_FUNC_ATTRIBUTE_NUM_REGS, f));
+    if (vgprs) *vgprs = (uint32_t)v;
+    HIPCHK(hipFuncGetAttribute(&v, HIP_FUNC_ATTRIBUTE_SHARED_SIZE_BYTES, f));
+    if (lds) *lds = (uint32_t)v;
     return GH_OK;
 }
 

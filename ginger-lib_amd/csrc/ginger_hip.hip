@@ -12,6 +12,7 @@
 #include <vector>
 #include "runtime.h"
 #include "scan_kernels.h"
+#include "asm_kernels.h"
 
 namespace gh_rt {
 
@@ -903,6 +904,21 @@ int gh_lagrange_coefficients(gh_field_t field, uint32_t log_n, const uint64_t* t
     if (!rc) rc = gh_dev_download(out, d, bytes);
     gh_dev_free(d);
     return rc;
+} catch (...) { return gh_rt::api_exception(); }
+
+int gh_measure_fpmul_peak(double* products_per_s) try {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!products_per_s) { g_err = "null argument"; return GH_E_BAD_ARG; }
+    int rc = ensure_init();
+    if (rc) return rc;
+    return gh_asm::measure_fpmul_peak(products_per_s, g.stream);
+} catch (...) { return gh_rt::api_exception(); }
+
+int gh_kernel_resources(const char* which, uint32_t* scratch_bytes_per_lane, uint32_t* registers, uint32_t* lds_bytes) try {
+    std::lock_guard<std::mutex> lk(g_mu);
+    int rc = ensure_init();
+    if (rc) return rc;
+    return gh_asm::kernel_resources(which, scratch_bytes_per_lane, registers, lds_bytes);
 } catch (...) { return gh_rt::api_exception(); }
 
 int gh_fft_last_kernel_ms(float* ms) try {

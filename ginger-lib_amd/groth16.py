@@ -333,10 +333,10 @@ class ResidentProvingKey:
         for rb in self.keys.values():
             rb.free()
 
-    def create_proof(self, circuit_rows, d1, d2, d3, r, s):
-        """create_proof (prover.rs:201-345) for evaluated constraint rows: circuit_rows = (num_inputs, assignment, A, B, C) as
-        Python integers (benchmark_circuit_rows); d1, d2, d3, r, s integers.  Returns Proof::write bytes (mod.rs:35-42)."""
-        gl = self.gl
+    def prepare_rows(self, circuit_rows, d1, d2, d3):
+        """The host side of create_proof up to the device boundary: the evaluated constraint rows (Python integers) as
+        Montgomery / canonical limb arrays, the way the reference holds them before the witness map (r1cs_to_qap.rs:100-120).
+        Separate from prove_prepared so that a caller (bench.py's `prover` object) can time the device stage alone."""
         pairing = self.pairing
         modulus = _MODULUS[pairing]
         num_inputs, assignment, A, B, C = circuit_rows
@@ -345,8 +345,6 @@ class ResidentProvingKey:
         size = 1
         while size < n_con + (num_inputs - 1) + 1:               # EvaluationDomain::new(num_constraints + num_inputs) (r1cs_to_qap.rs:100)
             size <<= 1
-        log_n = size.bit_length() - 1
-        field = "mnt4753_fr" if pairing == "mnt4753" else "mnt6753_fr"
         a = np.zeros((size, 12), dtype=np.uint64)
         b = np.zeros((size, 12), dtype=np.uint64)
         c = np.zeros((size, 12), dtype=np.uint64)
@@ -354,25 +352,47 @@ class ResidentProvingKey:
         b[:n_con] = _mont_rows(B, modulus)
         c[:n_con] = _mont_rows(C, modulus)
         a[n_con:n_con + num_inputs] = _mont_rows([1] + list(assignment[1:num_inputs]), modulus)     # :116-118
-        dd = _mont_rows([d1, d2, d3], modulus)
+        return {"size": size, "a": a, "b": b, "c": c, "dd": _mont_rows([d1, d2, d3], modulus), "scal": _canon_rows(assignment)}
+
+    def prove_prepared(self, prep, r, s, timing=None):
+        """create_proof (prover.rs:201-345) from prepare_rows' arrays: rows to the device, gh_witness_map_dev, into_repr on the
+        device, the five MSMs over the resident key, Proof::write bytes.  timing (a dict) receives wall-clock ms per stage."""
+        import time
+        gl, pairing = self.gl, self.pairing
+        size, num_inputs = prep["size"], self.num_inputs
+        log_n = size.bit_length() - 1
+        field = "mnt4753_fr" if pairing == "mnt4753" else "mnt6753_fr"
+        dd, scal = prep["dd"], prep["scal"]
         lib = gl.load_library()
+        t0 = time.perf_counter()
         bufs = [gl.DeviceBuffer(size * 96 + 96) for _ in range(4)]
         try:
-            for buf, arr in zip(bufs, (a, b, c)):
+            for buf, arr in zip(bufs, (prep["a"], prep["b"], prep["c"])):
                 buf.upload(arr)
+            lib.gh_dev_sync()
+            t1 = time.perf_counter()
             gl._check(lib.gh_witness_map_dev(gl.FIELDS[field], bufs[0].ptr, bufs[1].ptr, bufs[2].ptr, log_n, gl._ptr(dd[0]), gl._ptr(dd[1]),
                                              gl._ptr(dd[2]), bufs[3].ptr))
             one_plain = np.zeros(12, dtype=np.uint64)
             one_plain[0] = 1
             gl._check(lib.gh_vec_scale_dev(gl.FIELDS[field], bufs[3].ptr, gl._ptr(one_plain), size + 1))      # into_repr of h (:256-267)
-            scal = _canon_rows(assignment)
+            lib.gh_dev_sync()
+            t2 = time.perf_counter()
             self.pk = dict(self.pk, delta_g1=self.pk_delta_g1)
             A_, B_, C_ = self.create_proof_msms(scal[1:num_inputs], scal[num_inputs:], None, None, _canon_rows([r])[0], _canon_rows([s])[0],
                                                 h_dev=(bufs[3], self.keys["h"].n))
+            t3 = time.perf_counter()
         finally:
             for buf in bufs:
                 buf.free()
+        if timing is not None:
+            timing.update(rows_upload_ms=(t1 - t0) * 1e3, witness_map_ms=(t2 - t1) * 1e3, msm_stage_ms=(t3 - t2) * 1e3)
         return affine_to_wire(pairing, "g1", *A_) + affine_to_wire(pairing, "g2", *B_) + affine_to_wire(pairing, "g1", *C_)
+
+    def create_proof(self, circuit_rows, d1, d2, d3, r, s):
+        """create_proof (prover.rs:201-345) for evaluated constraint rows: circuit_rows = (num_inputs, assignment, A, B, C) as
+        Python integers (benchmark_circuit_rows); d1, d2, d3, r, s integers.  Returns Proof::write bytes (mod.rs:35-42)."""
+        return self.prove_prepared(self.prepare_rows(circuit_rows, d1, d2, d3), r, s)
 
     def create_proof_msms(self, input_assignment, aux_assignment, h_input_assignment, h_aux_assignment, r, s, h_dev=None):
         """All arguments are canonical 12-u64 scalars (rows).  Returns (A, B, C) as (xy, is_infinity) pairs:

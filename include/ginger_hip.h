@@ -285,6 +285,15 @@ int gh_lagrange_coefficients(gh_field_t field, uint32_t log_n, const uint64_t* t
 /* Duration of the kernels of the last gh_fft / gh_fft_dev call (HIP events), milliseconds. */
 int gh_fft_last_kernel_ms(float* ms);
 
+/* ---- measurement support (no counterpart in the reference) --------------------------------
+ * gh_measure_fpmul_peak: 753-bit Montgomery products per second of THIS card, measured now (about 30 ms): every lane of a
+ * full-chip launch runs two interleaved products per iteration on the register plan of the hot kernels (asmgen/microbench.py).
+ * bench.py prices `valu.frac` against it.  gh_kernel_resources: scratch bytes per lane (stack frame; spills), registers and
+ * LDS bytes of a generated kernel as the loaded code object reports them; `which` is one of g1_acc_p4, g1_acc_p6,
+ * g2_f2_fwd_r0, g2_f2_bwd_r0, g2_f2_bwd_rn, g2_f3_fwd_r0, g2_f3_bwd_r0, g2_f3_bwd_rn. */
+int gh_measure_fpmul_peak(double* products_per_s);
+int gh_kernel_resources(const char* which, uint32_t* scratch_bytes_per_lane, uint32_t* registers, uint32_t* lds_bytes);
+
 /* ---- device memory (plain pointers; for callers that keep vectors resident) -------------- */
 int gh_dev_alloc(void** d_ptr, size_t bytes);
 int gh_dev_free(void* d_ptr);
