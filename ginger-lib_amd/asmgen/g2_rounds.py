@@ -490,6 +490,7 @@ def build(name, cfg, fwd, r0, debug=False):
         g.global_store_dword(V_T2, V_O, S_FLAGP, offset=64)
         g.s_mov_b64(EXEC, VCC)
         g.global_store_dword(V_T1, V_T0, S_FLAGP)
+        g.global_store_dword(V_T1, V_T0, S_FLAGP, offset=16)        # sticky for the MSM: the host takes the key off the assembly rounds
         g.s_mov_b64(EXEC, S_T0)
         g.label(L_NOAPP)
         A1, A2, BS, M = E[1], E[2], [E[3], E[4], E[5]], E[7]

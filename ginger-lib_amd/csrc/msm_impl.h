@@ -402,6 +402,7 @@ struct MsmJob {
     bool tree = false;
     int tree_rounds = 0;
     uint32_t *aff_cnt = nullptr, *aff_st = nullptr, *aff_nout = nullptr;
+    bool aff_sticky_pending = false;
     uint32_t* hplan = nullptr;      // pinned
     Proj<C>* hw = nullptr;          // pinned, 9 RW points
     Aff<C>* salts = nullptr;
@@ -816,7 +817,7 @@ struct MsmJob {
         POOLBIG("aff_stage2", stage2, t64_bytes(tiles(max_n1), T64_PT_CHUNKS))
 #undef POOLBIG
         const uint32_t max_waves = (uint32_t)g.num_cus * 4u * (uint32_t)FS::WAVES;
-        const bool aff_asm = C::F::DEG >= 2 && gh_asm::aff_enabled();
+        const bool aff_asm = C::F::DEG >= 2 && gh_asm::aff_enabled() && !h->aff_asm_off;
         // the assembly kernels run two waves per SIMD; GH_AFF_WAVES_MUL x that many waves are launched so that the blocks (equal
         // work each) are dealt out dynamically instead of as one exact fill of the chip
         static const int env_wmul = getenv("GH_AFF_WAVES_MUL") ? atoi(getenv("GH_AFF_WAVES_MUL")) : 1;
@@ -828,6 +829,7 @@ struct MsmJob {
             if ((rc = pool_get(nm, t64_bytes((size_t)asm_max_waves + 4, T64_FP_CHUNKS), &asm_accs))) return rc;
             snprintf(nm, sizeof nm, "aff_flag#%d", slot);
             if ((rc = pool_get(nm, 64 + 4 * (size_t)AFF_FIX_CAP, (void**)&asm_flag))) return rc;   // control block + exception list
+            HIPCHK(hipMemsetAsync(asm_flag, 0, 64, st));                    // word 4: "a round of this MSM was redone" (sticky)
         }
         const Aff<C>* rows = (const Aff<C>*)(merged ? h->d_table : h->d_points);
         for (uint32_t j = 0; j < K; j++) {
@@ -907,6 +909,10 @@ struct MsmJob {
             }
         }
         HIPCHK(hipGetLastError());
+        if (aff_asm) {        // read with the window sums in finish(): a key that overflows the exception list leaves the assembly rounds
+            HIPCHK(hipMemcpyAsync(&hplan[16], asm_flag + 4, 4, hipMemcpyDeviceToHost, st));
+            aff_sticky_pending = true;
+        }
         n_heavy = 0;   // no chunk sums to combine
         return GH_OK;
     }
@@ -1003,6 +1009,7 @@ struct MsmJob {
             return GH_OK;
         }
         HIPCHK(hipEventSynchronize(g.pev[es][6]));
+        if (aff_sticky_pending && hplan[16] != 0) h->aff_asm_off = 1;
         auto t_fold0 = std::chrono::steady_clock::now();
         std::vector<Proj<C>> hwv(hw, hw + (size_t)9 * RW);
         if (lean) {

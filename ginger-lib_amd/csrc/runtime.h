@@ -101,6 +101,9 @@ struct BasesBase {
     int pre_c = 0, pre_W = 0;   // window bits, rows of the table
     int pre_G = 1;              // bucket sets: row j = 2^(pre_c pre_G j) P, window w = j pre_G + g reads row j and files into set g
                                 // (1 = full table, one bucket set; GH_TABLE_ROWS caps the rows: a partial table)
+    uint8_t aff_asm_off = 0;    // G2: an MSM over this key overflowed the exception list of the assembly rounds (a key with many equal
+                                // bases, e.g. a proving key's b_g2_query under an assignment with equal values: every pair of such bases
+                                // in a bucket is a doubling) -- later MSMs go straight to the C++ round kernel, which doubles inline
     uint32_t magic = 0x6768424au;
 };
 struct MsmOps {

@@ -554,6 +554,43 @@ def test_msm_affine_degenerate_inputs(gpu, curve):
         gpu.msm_set_affine(2)
 
 
+@pytest.mark.parametrize("curve", ["mnt4753_g2", "mnt6753_g2"])
+def test_g2_key_of_duplicate_bases_leaves_the_assembly_rounds(gpu, curve):
+    """A proving key's b_g2_query holds equal points wherever two variables have the same polynomial, and an assignment with
+    equal values sends both to the same bucket in every window: every such pair is a doubling (the reference's P == Q branch,
+    swp.rs:492).  The assembly rounds list such elements for aff_fix_kernel; when a round lists more than the list holds the
+    round is redone by the C++ kernel (which doubles inline) and the key stays on it for later MSMs (BasesBase::aff_asm_off).
+    Both calls must give sum s_i P_i, checked as twice the MSM over one copy of the bases (itself on the tested paths), and
+    an interleaved key with mostly distinct bases must still agree with the oracle-tested per-window path."""
+    C = pyref.CURVES[curve]
+    half = 1 << 15
+    rb_half = gpu.ResidentBases.chain(curve, *S.bases_array(C, S.chain_points(C, 2, pyref.Rng(61)))[0], half)
+    pts = rb_half.download(0, half)
+    s_half = S.random_scalars_np(half, seed=303, below=C.order)
+    dup = np.repeat(pts, 2, axis=0)                                   # P0 P0 P1 P1 ...: neighbours in every bucket list
+    s_dup = np.repeat(s_half, 2, axis=0)
+    rb = gpu.ResidentBases(curve, dup)
+    gpu.msm_set_affine(1)
+    try:
+        rb.precompute(0)
+        rb_half.precompute(0)
+        ref = gpu.proj_add(curve, rb_half.msm(s_half), rb_half.msm(s_half))
+        e_xy, e_inf = gpu.proj_to_affine(curve, ref)
+        for call in range(3):                                         # overflow + redo, then the sticky C++ path twice
+            g_xy, g_inf = gpu.proj_to_affine(curve, rb.msm(s_dup))
+            assert g_inf == e_inf and (g_xy == e_xy).all(), call
+        # the same key with other scalars (few coincidences): still correct on the path it was moved to
+        s2 = S.random_scalars_np(2 * half, seed=304, below=C.order)
+        a = gpu.proj_to_affine(curve, rb.msm(s2))
+        gpu.msm_set_affine(0)
+        b = gpu.proj_to_affine(curve, rb.msm(s2))
+        assert a[1] == b[1] and (a[0] == b[0]).all()
+    finally:
+        gpu.msm_set_affine(2)
+        rb.free()
+        rb_half.free()
+
+
 # ------------------------------------------------------------------------------ proving-key wire format
 def _wire(C, pts):
     """GroupAffine::write (short_weierstrass_projective.rs:185-192): x || y || infinity, each base-field
