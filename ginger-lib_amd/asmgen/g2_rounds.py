@@ -93,6 +93,16 @@ def build(name, cfg, fwd, r0, debug=False):
     chA = Chain(V(248, 2), V(252), V(253), S(14, 2), S(16, 2))
     chB = Chain(V(250, 2), V(254), V(255), S(18, 2), S(22, 2))
     L_START, L_LOOP, L_NEXT, L_END, L_BODY = (g.uniq(s) for s in ("start", "loop", "next", "end", "body"))
+    V_DEN = V(242) if r0 else V(238)      # the NEXT iteration's descriptor, fetched an iteration ahead (registers this kernel variant does
+                                          # not use otherwise: the + 4096 list address of later rounds / the list entries of round 0)
+
+    def fetch_desc(o_reg):
+        """V_DEN = desc[o] on the lanes whose element o exists (the others keep what they have: never used)"""
+        g.v_cmp_gt_u32(S_T0, S_NOUT, o_reg)
+        g.s_and_b64(EXEC, S_LIVE, S_T0)
+        g.v_lshlrev_b32(V_T0, 2, o_reg)
+        g.global_load_dword(V_DEN, V_T0, S_DESC)
+        g.s_mov_b64(EXEC, S_LIVE)
 
     def dbg(stage):
         """debug builds: flag[1 + wave of the block] = stage (tools/asm_g2_check.py)"""
@@ -362,7 +372,7 @@ def build(name, cfg, fwd, r0, debug=False):
     g.s_mul_i32(S_T1.lo(), S_K, FP_TILE)
     g.s_add_u32(S_ACCS.lo(), S_ACCS.lo(), S_T1.lo())
     g.s_addc_u32(S_ACCS.hi(), S_ACCS.hi(), S_T1.hi())
-    if r0 and fwd:
+    if r0:
         g.v_mul_u32_u24(V_T1, 104, V_COMP)
         g.v_add_co_u32(V_ROWB.lo(), VCC, S_IN.lo(), V_T1)
         g.v_mov_b32(V_T2, S_IN.hi())
@@ -374,6 +384,7 @@ def build(name, cfg, fwd, r0, debug=False):
         g.s_mov_b32(S_K, 0)
         g.v_mov_b32(V_OFF[0], V_LANE16)
         g.v_mov_b32(V_POFF[0], V_LANE16)
+        fetch_desc(V_O)
     else:
         g.v_mov_b32(V_POFF[0], V_LANE16)
         g.v_add_u32(V_POFF[1], 4096, V_LANE16)
@@ -387,6 +398,7 @@ def build(name, cfg, fwd, r0, debug=False):
         g.v_add_u32(V_POFF[0], S_TMP, V_LANE16)
         g.v_subrev_u32(V_POFF[0], FP_TILE, V_POFF[0])               # prefix of element k - 1
         g.s_waitcnt(vmcnt=0)
+        fetch_desc(V_O)
     g.s_branch(L_LOOP)
 
     # ------------------------------------------------------------ end
@@ -401,6 +413,21 @@ def build(name, cfg, fwd, r0, debug=False):
     # ------------------------------------------------------------ loop head
     g.label(L_LOOP)
     g.s_mov_b64(EXEC, S_LIVE)
+    g.s_waitcnt(vmcnt=0)                                            # the descriptor fetched an iteration ago (and this wave's stores)
+    g.v_mov_b32(V_DE, V_DEN)
+    # the next iteration's descriptor goes on its way now
+    L_NOPF = g.uniq("nopf")
+    if fwd:
+        g.s_add_u32(S_TMP, S_K, 1)
+        g.s_cmp_ge_u32(S_TMP, S_B)
+        g.s_cbranch_scc1(L_NOPF)
+        g.v_add_u32(V_T1, TPW, V_O)
+    else:
+        g.s_cmp_eq_u32(S_K, 0)
+        g.s_cbranch_scc1(L_NOPF)
+        g.v_subrev_u32(V_T1, TPW, V_O)
+    fetch_desc(V_T1)
+    g.label(L_NOPF)
     g.v_cmp_gt_u32(S_ACT, S_NOUT, V_O)
     g.s_and_b64(EXEC, EXEC, S_ACT)
     if fwd:
@@ -411,20 +438,20 @@ def build(name, cfg, fwd, r0, debug=False):
         g.long_branch(L_NEXT, S_T1)
     g.label(L_BODY)
     dbg(2)
-    g.v_lshlrev_b32(V_T0, 2, V_O)
-    g.global_load_dword(V_DE, V_T0, S_DESC)
     g.v_add_u32(V_OFF[1], 4096, V_OFF[0])
     g.v_add_u32(V_OFF[2], 12288, V_OFF[0])
     g.v_add_u32(V_POFF[1], 4096, V_POFF[0])
-    g.s_waitcnt(vmcnt=0)
     g.v_cmp_gt_i32(S_PAIR, 0, V_DE)                                 # bit 31: two inputs
     g.v_and_b32(V_DE, 0x7FFFFFFF, V_DE)
     g.v_cndmask_b32(V_T1, 0, 1, S_PAIR)
 
     X1, X2 = E[1], E[6]
-    if fwd and r0:
-        Y1, Y2 = E[2], E[3]
-        # the two list entries -> rows
+    # backward kernel on lane pairs: E4 and E7 are free until lambda is formed, so y1 and y2 travel with x1 and x2 (one exposed
+    # memory latency less per element); lane triples need all eight slots for the two products in between
+    early_y = (not fwd) and L == 2
+    def r0_rows():
+        """round 0: the two list entries of the element (V_E1, V_E2: row | sign << 31) and the addresses of this lane's coefficient in
+        their table rows (V_ADDR1, V_ADDR2)"""
         g.v_mad_u64_u32(V_ADDR1, chA.sdum, V_DE, 4, S_SORTED)
         g.v_add_u32(V_T2, V_DE, V_T1)
         g.v_mad_u64_u32(V_ADDR2, chA.sdum, V_T2, 4, S_SORTED)
@@ -436,29 +463,42 @@ def build(name, cfg, fwd, r0, debug=False):
         g.v_mad_u64_u32(V_ADDR1, chA.sdum, V_T2, S_TMP, V_ROWB)
         g.v_and_b32(V_T2, 0x7FFFFFFF, V_E2)
         g.v_mad_u64_u32(V_ADDR2, chA.sdum, V_T2, S_TMP, V_ROWB)
-        # every lane group reads its own rows: a quarter of the wave at a time, all loads of its rows back to back, so that the
-        # address translations of its pages stay resident (aff_kernels.h gather_row: 13 TLB misses per row without it)
+
+    def r0_gather(parts):
+        """parts: (slot, address pair, byte offset in the row) -- every lane group reads its own rows: a quarter of the wave at a time,
+        all loads of its rows back to back, so that the address translations of its pages stay resident (aff_kernels.h gather_row:
+        13 TLB misses per row without it).  The caller waits."""
         g.s_mov_b64(S_T0, EXEC)
         for q in range(4):
             g.s_bfm_b64(S_T1, 16, 16 * q)
             g.s_and_b64(EXEC, S_T0, S_T1)
-            for sl, addr, off in ((X1, V_ADDR1, 0), (Y1, V_ADDR1, L * 104), (X2, V_ADDR2, 0), (Y2, V_ADDR2, L * 104)):
+            for sl, addr, off in parts:
                 for j in range(NL // 2):
                     g.global_load_dwordx2(V(sl.idx + 2 * j, 2), addr, OFF, offset=off + 8 * j)
         g.s_mov_b64(EXEC, S_T0)
-        g.s_waitcnt(vmcnt=0)
+
+    def r0_signs(y1, y2):
+        """the signs of the two list entries on the ordinates"""
         g.v_cmp_gt_i32(S_T0, 0, V_E1)
-        run(f.neg_sel(chA, Y1, V_TMP, S_T0))
+        run(f.neg_sel(chA, y1, V_TMP, S_T0))
         g.v_cmp_gt_i32(S_T0, 0, V_E2)
-        run(f.neg_sel(chB, Y2, V_TMP, S_T0))
-        st_x_list(X1, S_STAGE1, V_OFF)
-        st_y_list(Y1, S_STAGE1, V_OFF)
-        st_x_list(X2, S_STAGE2, V_OFF)
-        st_y_list(Y2, S_STAGE2, V_OFF)
-    elif r0:
-        ld_x_list(X1, S_STAGE1, V_OFF)
-        ld_x_list(X2, S_STAGE2, V_OFF)
+        run(f.neg_sel(chB, y2, V_TMP, S_T0))
+
+    # Round 0 reads the table rows in BOTH kernels (no staged copy: the forward kernel needs the abscissae only, and staging
+    # 832 B per element made it the one memory-bound kernel of an MSM -- 39 GB in 11.8 ms at 2^20 MNT4-753 G2 pairs)
+    if fwd and r0:
+        r0_rows()
+        r0_gather([(X1, V_ADDR1, 0), (X2, V_ADDR2, 0)])
         g.s_waitcnt(vmcnt=0)
+    elif r0:
+        r0_rows()
+        if early_y:
+            r0_gather([(X1, V_ADDR1, 0), (E[4], V_ADDR1, L * 104), (X2, V_ADDR2, 0), (E[7], V_ADDR2, L * 104)])
+            g.s_waitcnt(vmcnt=0)
+            r0_signs(E[4], E[7])
+        else:
+            r0_gather([(X1, V_ADDR1, 0), (X2, V_ADDR2, 0)])
+            g.s_waitcnt(vmcnt=0)
     else:
         g.v_subrev_u32(V_T0, S_INBASE, V_DE)
         list_addr(V_T0, V_ADDR1, V_A1B, V_A1C)
@@ -466,6 +506,9 @@ def build(name, cfg, fwd, r0, debug=False):
         list_addr(V_T0, V_ADDR2, V_A2B, V_A2C)
         ld_x_list(X1, None, [V_ADDR1, V_A1B, V_A1C])
         ld_x_list(X2, None, [V_ADDR2, V_A2B, V_A2C])
+        if early_y:
+            ld_y_list(E[4], None, [V_ADDR1, V_A1B, V_A1C])
+            ld_y_list(E[7], None, [V_ADDR2, V_A2B, V_A2C])
         g.s_waitcnt(vmcnt=0)
 
     if fwd:
@@ -525,17 +568,22 @@ def build(name, cfg, fwd, r0, debug=False):
     A1, A2, BS = E[3], E[4], [E[5], E[6], E[7]]
     g.s_waitcnt(lgkmcnt=0)                                          # X2 (= E6) is a broadcast target below: parked first
     prep_b(D, BS)
+    # prefix_(k-1) into d's slot (its broadcasts are on their way): in flight during the first product
+    PK = E[2]
+    L_PKE = g.uniq("pkearly")
+    g.s_cmp_eq_u32(S_K, 0)
+    g.s_cbranch_scc1(L_PKE)
+    ld_fp_list(PK, S_PREFIX, V_POFF)
+    g.label(L_PKE)
     prep_a(INV, A1, A2)
     M1 = E[1]
     dbg(4)
     tower_mul(INV, A1, A2, BS, M1, BS[0])                           # inv (x) d: the inverse of the elements before this one
     dbg(5)
     # 1 / d_k = inv (x) prefix_(k-1)
-    PK = E[2]
     L_PK0, L_PKD = g.uniq("pk0"), g.uniq("pkd")
     g.s_cmp_eq_u32(S_K, 0)
     g.s_cbranch_scc1(L_PK0)
-    ld_fp_list(PK, S_PREFIX, V_POFF)
     g.s_waitcnt(vmcnt=0)
     g.s_branch(L_PKD)
     g.label(L_PK0)
@@ -546,14 +594,18 @@ def build(name, cfg, fwd, r0, debug=False):
     tower_mul(INV, A1, A2, BS, DI, BS[0])
     select(INV, INV, M1, S_PAIR)                                    # a copy leaves the running inverse alone
     # lambda = (y2 - y1) / d
-    Y1, NUM = E[1], E[3]
-    if r0:
-        ld_y_list(Y1, S_STAGE1, V_OFF)
-        ld_y_list(NUM, S_STAGE2, V_OFF)
+    if early_y:
+        Y1, NUM = E[4], E[7]
     else:
-        ld_y_list(Y1, None, [V_ADDR1, V_A1B, V_A1C])
-        ld_y_list(NUM, None, [V_ADDR2, V_A2B, V_A2C])
-    g.s_waitcnt(vmcnt=0)
+        Y1, NUM = E[1], E[3]
+        if r0:
+            r0_gather([(Y1, V_ADDR1, L * 104), (NUM, V_ADDR2, L * 104)])
+            g.s_waitcnt(vmcnt=0)
+            r0_signs(Y1, NUM)
+        else:
+            ld_y_list(Y1, None, [V_ADDR1, V_A1B, V_A1C])
+            ld_y_list(NUM, None, [V_ADDR2, V_A2B, V_A2C])
+            g.s_waitcnt(vmcnt=0)
     park_put(PY1, Y1)
     run(f.sub(chA, NUM, Y1, NUM))
     A1, A2 = E[4], E[1]

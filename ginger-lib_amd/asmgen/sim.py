@@ -166,6 +166,51 @@ class Wave:
             return self.S[o.idx]
         return o & M32
 
+    # ---- asynchronous results: a register that a memory / LDS instruction will write is "in flight" until the s_waitcnt that
+    #      covers it (vmcnt(0) / lgkmcnt(0); partial counts are not modelled: they clear nothing).  Any other instruction that reads or
+    #      writes such a register in between is a missing wait -- on the card it would see (or be overwritten by) stale data.
+    def _check_inflight(self, i):
+        op = i.op
+        if op == "s_waitcnt":
+            if i.mods.get("vmcnt") == 0:
+                self._inflight_vm = set()
+            if i.mods.get("lgkmcnt") == 0:
+                self._inflight_lgkm = set()
+            return
+        vm = getattr(self, "_inflight_vm", None)
+        if vm is None:
+            vm = self._inflight_vm = set()
+            self._inflight_lgkm = set()
+        lg = self._inflight_lgkm
+        regs = set()
+        for a in i.args:
+            if isinstance(a, Reg) and a.kind in ("v", "a"):
+                base = a.idx + (256 if a.kind == "a" else 0)
+                regs.update(range(base, base + a.n))
+            elif isinstance(a, Reg) and a.kind == "s":
+                regs.update(-1 - r for r in range(a.idx, a.idx + a.n))       # SGPRs as negative keys (s_load results)
+        own = set()
+        if op.startswith("global_load") and isinstance(i.args[0], Reg):       # the same destination again under another EXEC mask (a
+            d0 = i.args[0]                                                    # gather a quarter of the wave at a time): loads return in order
+            own = set(range(d0.idx, d0.idx + d0.n)) & vm
+        hit = (regs - own) & (vm | lg)
+        if hit:
+            raise RuntimeError("%s touches a register with a result in flight (no s_waitcnt): %s" % (
+                i.text().strip(), sorted(("v%d" % r) if r >= 0 else ("s%d" % (-1 - r)) for r in hit)[:6]))
+        dst = None
+        if op.startswith("global_load") or (op.startswith("global_atomic") and i.mods.get("sc0")):
+            dst, pend = i.args[0], vm
+        elif op.startswith("ds_read") or op in ("ds_bpermute_b32", "ds_permute_b32", "ds_swizzle_b32"):
+            dst, pend = i.args[0], lg
+        elif op.startswith("s_load"):
+            dst, pend = i.args[0], lg
+        if dst is not None:
+            if dst.kind in ("v", "a"):
+                base = dst.idx + (256 if dst.kind == "a" else 0)
+                pend.update(range(base, base + dst.n))
+            else:
+                pend.update(-1 - r for r in range(dst.idx, dst.idx + dst.n))
+
     # ---- run
     def run(self, max_steps=50_000_000):
         pc = 0
@@ -181,6 +226,7 @@ class Wave:
                     continue
                 self.executed += 1
                 self.hist[op] = self.hist.get(op, 0) + 1
+                self._check_inflight(i)
                 if self.executed > max_steps:
                     raise RuntimeError("step limit")
                 if op == "s_endpgm":

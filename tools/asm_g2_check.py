@@ -108,7 +108,7 @@ def main():
             print("  MISMATCH against the group law:", str(e)[:200])
     print("flag cases")
     try:
-        T.test_g2_round_kernel_flags_the_rare_cases("mnt4753_g2")
+        T.test_g2_round_kernels_list_the_rare_cases("mnt4753_g2")
         print("  ok")
     except AssertionError as e:
         ok = False

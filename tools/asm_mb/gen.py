@@ -8,7 +8,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "ginger-lib_amd"))
-from asmgen.isa import Prog, V, S, VCC, EXEC, OFF, module_text          # noqa: E402
+from asmgen.isa import Prog, V, S, VCC, EXEC, OFF, module_text, fix_hazards          # noqa: E402
 from asmgen.field import FieldGen, Chain, interleave, run, NL, LM      # noqa: E402
 from asmgen import g1_xyzz                                             # noqa: E402
 from asmgen.build import P4, LLVM                                      # noqa: E402
@@ -211,6 +211,71 @@ def _(g, f, A, B):
     return 2
 
 
+# ---- building blocks of the G2 round kernels (asmgen/g2_rounds.py).  kernel() sets up: v8 = 4 (lane ^ 1), v10 / v11 = 4 x the
+#      even / odd lane of the pair, v9 / v12 = 4 x other lanes of a triple, v6 / v7 = 13 on even lanes else 1, s[88:89] = 1 / (p_25 + 1)
+@block("g2_triple")
+def _(g, f, A, B):
+    run(f.triple(A, B, [(E[0], E[3]), (E[1], E[4]), (E[2], E[5])], E[6], E[7]))
+    return 1
+
+
+@block("g2_mul_small_single")
+def _(g, f, A, B):
+    run(f.mul_small(A, E[0], V(6), E[6], S(88, 2)))
+    return 1
+
+
+@block("g2_mul_small_pair")
+def _(g, f, A, B):
+    interleave(f.mul_small(A, E[0], V(6), E[6], S(88, 2)), f.mul_small(B, E[1], V(7), E[7], S(88, 2)))
+    return 2
+
+
+@block("g2_bperm3_wait")
+def _(g, f, A, B):
+    run(f.bperm(E[5], V(10), E[0]))
+    run(f.bperm(E[6], V(11), E[0]))
+    run(f.bperm(E[7], V(8), E[1]))
+    g.s_waitcnt(lgkmcnt=0)
+    return 1
+
+
+@block("g2_tower2")
+def _(g, f, A, B):
+    # one Fq2 tower product as the round kernels issue it: broadcasts of b, swap + scale of a, dual product
+    run(f.bperm(E[5], V(10), E[2]))
+    run(f.bperm(E[6], V(11), E[2]))
+    run(f.bperm(E[3], V(8), E[0]))
+    g.s_waitcnt(lgkmcnt=0)
+    run(f.mul_small(A, E[3], V(6), E[3], S(88, 2)))
+    g.s_waitcnt(lgkmcnt=0)
+    run(f.dual(A, B, E[0], E[5], E[3], E[6], E[1], E[5]))
+    return 1
+
+
+@block("g2_tower3")
+def _(g, f, A, B):
+    for dst, addr in ((E[5], V(10)), (E[6], V(11)), (E[7], V(12))):
+        run(f.bperm(dst, addr, E[2]))
+    run(f.bperm(E[3], V(8), E[0]))
+    run(f.bperm(E[4], V(9), E[0]))
+    g.s_waitcnt(lgkmcnt=0)
+    interleave(f.mul_small(A, E[3], V(6), E[3], S(88, 2)), f.mul_small(B, E[4], V(7), E[4], S(88, 2)))
+    g.s_waitcnt(lgkmcnt=0)
+    run(f.triple(A, B, [(E[0], E[5]), (E[3], E[6]), (E[4], E[7])], E[1], E[5]))
+    return 1
+
+
+@block("g2_dual_seq5_subs")
+def _(g, f, A, B):
+    # the arithmetic of one backward iteration without memory, exchanges or parks: 5 dual products + 6 subtractions
+    for _ in range(5):
+        run(f.dual(A, B, E[0], E[5], E[3], E[6], E[1], E[5]))
+    for _ in range(6):
+        run(f.sub(A, E[4], E[2], E[4]))
+    return 1
+
+
 def _phase_block(pa, pb, pm, beta, kind="mul"):
     # slots with base register = pa / pb / pm (mod 4), accumulator pair at bank beta
     bases = {0: [40, 68, 96], 2: [126, 154, 182], 1: [41 + 170, 0, 0], 3: [0, 0, 0]}
@@ -267,6 +332,16 @@ def kernel(name, fn):
     f.load_constants()
     g.v_lshlrev_b32(V(1), 2, V(0))
     g.s_mov_b32(S(78), 0x0F0F3355); g.s_mov_b32(S(79), 0xAAAA00FF)
+    lo_, hi_ = f.invc_bits()
+    g.s_mov_b32(S(88), lo_); g.s_mov_b32(S(89), hi_)
+    g.v_and_b32(V(34), 63, V(0))
+    g.v_xor_b32(V(35), 1, V(34)); g.v_lshlrev_b32(V(8), 2, V(35))
+    g.v_and_b32(V(35), 62, V(34)); g.v_lshlrev_b32(V(10), 2, V(35))
+    g.v_or_b32(V(35), 1, V(34)); g.v_lshlrev_b32(V(11), 2, V(35))
+    g.v_xor_b32(V(35), 2, V(34)); g.v_lshlrev_b32(V(9), 2, V(35)); g.v_lshlrev_b32(V(12), 2, V(35))
+    g.v_and_b32(V(35), 1, V(34)); g.v_cmp_eq_u32(S(80, 2), 0, V(35))
+    g.v_mov_b32(V(36), 1); g.v_mov_b32(V(37), 13)
+    g.v_cndmask_b32(V(6), V(36), V(37), S(80, 2)); g.v_cndmask_b32(V(7), V(36), V(37), S(80, 2))
     # operands: limbs derived from the lane id, below 2^29, top limb small so that values stay below p
     for i in range(8):
         for w in range(NL):
@@ -289,6 +364,7 @@ def kernel(name, fn):
     g.long_branch(L, S(94, 2))
     g.label(Lx)
     g.s_endpgm()
+    fix_hazards(g)
     return g, units
 
 
