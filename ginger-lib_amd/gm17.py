@@ -20,7 +20,7 @@ would (short_weierstrass_projective.rs:185-192), which is what the parity tests 
 """
 import numpy as np
 
-from .groth16 import _MODULUS, _canon_rows, _mont_rows, affine_to_wire
+from .groth16 import _MODULUS, _canon_rows, _canon_rows_fast, _ints_from_mont_rows, _mont_rows, affine_to_wire
 
 
 def sap_rows_from_r1cs(pairing, num_inputs, assignment, A, B, C):
@@ -76,9 +76,20 @@ class ResidentGm17Key:
             "c2": (self.g1, cat(pk["c_query_2"][1:], row(pk["c_query_2"][0]))),
             "g": (self.g1, cat(pk["g_gamma2_z_t"], row(pk["g_gamma2_z_t"][0]))),
         }
+        # keys made by generate_parameters hold GroupAffine::zero() wherever a variable does not occur in A (the extra SAP
+        # variables: r1cs_to_sap.rs:68, :85-91): pk["<query>_inf"] flags them (absent = all finite)
+        def flags(q, head_last, tail):
+            f = pk.get(q + "_inf")
+            if f is None:
+                return None
+            f = np.asarray(f, dtype=np.uint8)
+            f = np.concatenate([f[1:], f[:1]]) if head_last else f
+            return np.ascontiguousarray(np.concatenate([f, np.zeros(tail, dtype=np.uint8)]))
+        inf = {"a": flags("a_query", True, 1), "b": flags("b_query", True, 1), "c1": flags("c_query_1", False, 2),
+               "c2": flags("c_query_2", True, 0), "g": None}
         self.keys = {}
         for name, (curve, rows) in vectors.items():
-            rb = gl.ResidentBases(curve, rows)
+            rb = gl.ResidentBases(curve, rows, infinity=inf[name])
             if precompute and rb.n:
                 try:
                     rb.precompute(0)
@@ -180,6 +191,104 @@ class ResidentGm17Key:
         finally:
             for buf in bufs:
                 buf.free()
+
+
+def generate_parameters(gl, pairing, lcs, alpha, beta, gamma, t, g1_xyz, g2_xyz):
+    """generate_parameters (proof-systems/src/gm17/generator.rs:146-335) above the C ABI, for a constraint system given as linear
+    combinations (groth16.benchmark_circuit_lcs form); the toxic waste alpha, beta, gamma, the evaluation point t
+    (sample_element_outside_domain, :183) and the generators g, h (`rand`, :41-42) are arguments instead of RNG draws.
+      * Lagrange coefficients at t on the device (gh_lagrange_coefficients = evaluate_all_lagrange_coefficients, domain.rs:183-219);
+      * R1CStoSAP::instance_map_with_evaluation (r1cs_to_sap.rs:14-96): host integers, as in the reference;
+      * the FIVE FixedBaseMSM::multi_scalar_mul calls (:222-229 a_query, :245-254 g_gamma2_z_t, :259-270 verifier query ||
+        c_query_1, :274-285 c_query_2, :297-302 b_query on h^gamma) with the reference's window rule (:198-213, :290) followed
+        by batch_normalization + into_affine (:323-333): gh_fixed_base_msm_affine;
+      * the single points (:233-241) by host-side scalar multiplications (gh_proj_mul).
+    Returns (pk, info): pk in ResidentGm17Key's form (Montgomery x || y rows + `<query>_inf` flags; GM17's Parameters::write is
+    unimplemented upstream, gm17/mod.rs:186-196), info = the SAP evaluations a, c, Z(t) for a check in the exponent."""
+    r = _MODULUS[pairing]
+    field = "mnt4753_fr" if pairing == "mnt4753" else "mnt6753_fr"
+    g1c, g2c = pairing + "_g1", pairing + "_g2"
+    num_inputs, num_aux, at, bt, ct = lcs
+    n_con = len(at)
+    ni1 = num_inputs - 1
+    size = 1
+    while size < 2 * n_con + 2 * ni1 + 1:                                          # r1cs_to_sap.rs:18-21
+        size <<= 1
+    log_n = size.bit_length() - 1
+    zt = (pow(t, size, r) - 1) % r
+    u_rows = np.zeros((size, 12), dtype=np.uint64)
+    gl._check(gl.load_library().gh_lagrange_coefficients(gl.FIELDS[field], log_n, gl._ptr(_mont_rows([t], r)[0]), gl._ptr(u_rows)))
+    u = _ints_from_mont_rows(u_rows, r)
+    sap_nv = 2 * ni1 + num_aux + n_con                                             # :30-31
+    xvo, xco, xvo2 = ni1 + num_aux + 1, 2 * n_con, ni1 + num_aux + n_con           # :32-35
+    a, c = [0] * (sap_nv + 1), [0] * (sap_nv + 1)
+    for i in range(n_con):                                                         # :40-73
+        u0, u1 = u[2 * i], u[2 * i + 1]
+        ua, us = (u0 + u1) % r, (u0 - u1) % r
+        for cf, ix in at[i]:
+            a[ix] = (a[ix] + ua * cf) % r
+        for cf, ix in bt[i]:
+            a[ix] = (a[ix] + us * cf) % r
+        for cf, ix in ct[i]:
+            c[ix] = (c[ix] + 4 * u0 * cf) % r
+        c[xvo + i] = (c[xvo + i] + ua) % r
+    a[0] = (a[0] + u[xco]) % r                                                     # :75-76
+    c[0] = (c[0] + u[xco]) % r
+    for i in range(1, ni1 + 1):                                                    # :78-94
+        uo, ue = u[xco + 2 * i - 1], u[xco + 2 * i]
+        a[i] = (a[i] + uo + ue) % r
+        a[0] = (a[0] + uo - ue) % r
+        c[i] = (c[i] + 4 * uo) % r
+        c[xvo2 + i] = (c[xvo2 + i] + uo + ue) % r
+    non_zero_a = sum(1 for v in a[:sap_nv] if v)                                   # generator.rs:191-195
+    m_raw = size
+    FB = gl.FixedBaseMSM
+    g_window = FB.get_mul_window_size(num_inputs + non_zero_a + (sap_nv - ni1) + sap_nv + 1 + m_raw + 1)      # :198-211
+    h_window = FB.get_mul_window_size(non_zero_a)                                  # :290
+    ab = (alpha + beta) % r
+    gz = gamma * zt % r
+    stats = {"fixed_base_scalars": 0, "fixed_base_calls": 0}
+
+    def rows(table, vals):
+        xy, inf = table.multi_scalar_mul_affine(_canon_rows_fast(vals), canonical=False)
+        stats["fixed_base_scalars"] += len(vals)
+        stats["fixed_base_calls"] += 1
+        return np.ascontiguousarray(xy, dtype=np.uint64), np.asarray(inf, dtype=np.uint8)
+
+    def point(curve, xyz, k):
+        xy, inf = gl.proj_to_affine(curve, gl.proj_mul(curve, xyz, _canon_rows([k % r])[0]))
+        assert not inf
+        return np.asarray(xy, dtype=np.uint64).reshape(-1)
+
+    pk = {}
+    tg = FB(g1c, g1_xyz, 753, g_window)
+    try:
+        pk["a_query"], pk["a_query_inf"] = rows(tg, [v * gamma % r for v in a])
+        g2zt = gz * gamma % r
+        pw, cur = [], g2zt
+        for _ in range(m_raw + 1):
+            pw.append(cur)
+            cur = cur * t % r
+        pk["g_gamma2_z_t"], ginf = rows(tg, pw)
+        assert not ginf.any()
+        res, rinf = rows(tg, [(cv * gamma + av * ab) % r for av, cv in zip(a, c)])
+        pk["verifier_query"], pk["c_query_1"], pk["c_query_1_inf"] = res[:num_inputs], res[num_inputs:], rinf[num_inputs:]
+        pk["c_query_2"], pk["c_query_2_inf"] = rows(tg, [v * (2 * gamma * gamma % r) % r * zt % r for v in a])
+    finally:
+        tg.free()
+    h_gamma = gl.proj_mul(g2c, g2_xyz, _canon_rows([gamma % r])[0])
+    th = FB(g2c, h_gamma, 753, h_window)
+    try:
+        pk["b_query"], pk["b_query_inf"] = rows(th, a)
+    finally:
+        th.free()
+    pk["g_gamma_z"] = point(g1c, g1_xyz, gz)
+    pk["h_gamma_z"] = point(g2c, h_gamma, zt)
+    pk["g_ab_gamma_z"] = point(g1c, g1_xyz, ab * gz)
+    pk["g_gamma2_z2"] = point(g1c, g1_xyz, gz * gz)
+    info = {"num_inputs": num_inputs, "log_n": log_n, "sap": (a, c, zt), "sap_num_variables": sap_nv, "g_window": g_window,
+            "h_window": h_window, "non_zero_a": non_zero_a, "fixed_base": stats}
+    return pk, info
 
 
 def proof_bytes(pairing, proof):

@@ -136,3 +136,55 @@ def test_gm17_create_proof_end_to_end_vs_oracle(gpu, pairing, n_con, precompute)
     exp = _oracle_gm17_stage(pairing, pk, ni, scal[1:ni], scal[ni:], h_ints[:ni], h_ints[ni:], d1, d2, r)
     for name, (gxy, ginf), (exy, einf) in zip("ABC", got, exp):
         assert ginf == einf and (np.asarray(gxy) == np.asarray(exy)).all(), (pairing, name)
+
+
+@pytest.mark.gpu
+def test_gm17_key_generated_on_device_and_proof_in_closed_form(gpu):
+    """GM17 to Groth16's standard of evidence: the proving key of the `Benchmark` circuit with 2^16 - 3
+    constraints (SAP domain 2^17) is GENERATED on the device -- gm17.generate_parameters mirrors generator.rs:146-335 with its
+    five FixedBaseMSM::multi_scalar_mul calls on gh_fixed_base_msm_affine --, made resident, and used by create_proof
+    (prover.rs:201-352: SAP witness map on the device, five MSMs).  A, B, C are then compared with GM17's equations
+    evaluated IN THE EXPONENT from the toxic waste with Python integers and three textbook scalar multiplications:
+        A = gamma (sum a_i(t) x_i + r Z(t)) g,   B = the same scalar on h,
+        C = (sum_aux x_i (gamma c_i(t) + (alpha + beta) a_i(t)) + r^2 gamma^2 Z^2 + r (alpha + beta) gamma Z
+             + 2 r gamma^2 Z sum a_i x_i + gamma^2 ((sum a_i x_i)^2 - sum c_i x_i)) g
+    (d1 = d2 = 0; the last term is gamma^2 Z(t) H(t) by the SAP's divisibility) -- no MSM or FFT code path involved."""
+    import time
+    gm17 = importlib.import_module("ginger_lib_amd.gm17")
+    groth16 = importlib.import_module("ginger_lib_amd.groth16")
+    pairing = "mnt4753"
+    C1, C2 = pyref.CURVES[pairing + "_g1"], pyref.CURVES[pairing + "_g2"]
+    r = C1.order
+    n_con = (1 << 16) - 3
+    rng = pyref.Rng(417)
+    alpha, beta, gamma, t, r_ = (rng.field_elem(r) for _ in range(5))
+    g1, g2 = C1.mul(rng.next_u64() | 1, C1.G), C2.mul(rng.next_u64() | 1, C2.G)
+    t0 = time.perf_counter()
+    lcs = groth16.benchmark_circuit_lcs(n_con)
+    pk, info = gm17.generate_parameters(gpu, pairing, lcs, alpha, beta, gamma, t, S.proj_array(C1, g1), S.proj_array(C2, g2))
+    t_gen = time.perf_counter() - t0
+    assert info["log_n"] == 17 and info["fixed_base"]["fixed_base_calls"] == 5
+    assert int(pk["a_query_inf"].sum()) == sum(1 for v in info["sap"][0] if v == 0) > 0        # the extra SAP variables do not occur in A
+    rows = groth16.benchmark_circuit_rows(pairing, n_con)
+    key = gm17.ResidentGm17Key(gpu, pairing, pk, 3)
+    try:
+        t0 = time.perf_counter()
+        proof = key.create_proof(rows, 0, 0, r_)
+        t_proof = time.perf_counter() - t0
+    finally:
+        key.free()
+        gpu.dev_trim()
+    print("gm17 generate %.1f s (%d fixed-base scalar-muls in 5 calls, windows g %d h %d), create_proof %.2f s" % (
+        t_gen, info["fixed_base"]["fixed_base_scalars"], info["g_window"], info["h_window"], t_proof))
+    a, c, zt = info["sap"]
+    full, _, _, _ = gm17.sap_rows_from_r1cs(pairing, 3, rows[1], rows[2], rows[3], rows[4])
+    assert len(full) == len(a) == info["sap_num_variables"] + 1
+    sa = sum(x * y for x, y in zip(full, a)) % r
+    sc = sum(x * y for x, y in zip(full, c)) % r
+    ab = (alpha + beta) % r
+    A_s = gamma * (sa + r_ * zt) % r
+    C_s = (sum(full[i] * (gamma * c[i] + ab * a[i]) for i in range(3, len(full))) + r_ * r_ * gamma * gamma % r * zt * zt
+           + r_ * ab * gamma % r * zt + 2 * r_ * gamma * gamma % r * zt * sa + gamma * gamma * (sa * sa - sc)) % r
+    import groth16_ref as G
+    exp = G.wire(C1, C1.mul(A_s, g1)) + G.wire(C2, C2.mul(A_s, g2)) + G.wire(C1, C1.mul(C_s, g1))
+    assert gm17.proof_bytes(pairing, proof) == exp
