@@ -23,6 +23,7 @@ struct Rccl {
     std::string path;          // the file the symbols come from (dladdr)
     int version = 0;           // ncclGetVersion
     bool was_mapped = false;   // an RCCL was already in the process (e.g. torch's) and is the one in use
+    std::string note;          // why a mapped copy was passed over (major version other than the build headers')
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
@@ -57,6 +58,24 @@ int load_rccl() {
     void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
     if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
     R.was_mapped = h != nullptr;
+    R.note.clear();
+    if (h) {
+        // ... unless its ABI generation is not the one this library was compiled against (rccl.h NCCL_MAJOR): ncclUniqueId,
+        // ncclComm_t and the call signatures are only promised within a major version.  Then the ROCm installation's copy is
+        // loaded by path next to it, and gh_dist_transport says so.
+        ncclResult_t (*gv)(int*) = nullptr;
+        *reinterpret_cast<void**>(&gv) = dlsym(h, "ncclGetVersion");
+        int v = 0;
+        if (gv && gv(&v) == ncclSuccess && v / 10000 != NCCL_MAJOR) {
+            char b[160];
+            snprintf(b, sizeof b, "the RCCL already mapped by the host process is %d.%d.%d, built against %d.x: using the ROCm copy", v / 10000,
+                     (v / 100) % 100, v % 100, NCCL_MAJOR);
+            R.note = b;
+            dlclose(h);
+            h = nullptr;
+            R.was_mapped = false;
+        }
+    }
     if (!h) {
         const char* env = getenv("GH_RCCL_PATH");
         const char* rocm = getenv("ROCM_PATH");
@@ -226,7 +245,9 @@ int gh_dist_transport(int* rccl_ranks, int* rccl_version, char* path, size_t pat
     if (D.ready && D.comm) { int c = 0; if (R.CommCount(D.comm, &c) == ncclSuccess) ranks = c; }
     if (rccl_ranks) *rccl_ranks = ranks;                   // 0: no RCCL communicator (custom transport or none)
     if (rccl_version) *rccl_version = R.lib ? R.version : 0;
-    if (path && path_cap) snprintf(path, path_cap, "%s%s", R.lib ? R.path.c_str() : "", R.lib && R.was_mapped ? " (already mapped by the host process)" : "");
+    if (path && path_cap)
+        snprintf(path, path_cap, "%s%s%s%s%s", R.lib ? R.path.c_str() : "", R.lib && R.was_mapped ? " (already mapped by the host process, same major version as the build headers)" : "",
+                 R.note.empty() ? "" : " (", R.note.c_str(), R.note.empty() ? "" : ")");
     return GH_OK;
 } catch (...) { return gh_rt::api_exception(); }
 

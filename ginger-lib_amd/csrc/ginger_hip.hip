@@ -126,7 +126,16 @@ int scratch_guard(const void* kernel, size_t threads) {
 int pool_get(const char* name, size_t bytes, void** out) {
     DevBuf& b = g.pool[name];
     if (b.cap < bytes) {
-        if (b.p) { HIPCHK(hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+        if (b.p) {
+            // A pipelined batch re-uses a slot's buffers two jobs later, while the job before may still be reducing out of them
+            // (msm_batch issues sort(k+1) before finish(k-1)): a LARGER job in that position replaces buffers that are in use.
+            // Nothing may be freed under a running kernel -- wait for the device first (explicitly: not left to hipFree's implicit
+            // synchronisation).  Growth is rare (the pool keeps 1/8 of slack); equal or shrinking jobs never come here.
+            HIPCHK(hipDeviceSynchronize());
+            HIPCHK(hipFree(b.p));
+            b.p = nullptr;
+            b.cap = 0;
+        }
         size_t cap = bytes + bytes / 8 + 256;
         HIPCHK(hipMalloc(&b.p, cap));
         b.cap = cap;

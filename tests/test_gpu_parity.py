@@ -481,6 +481,37 @@ def test_msm_batch_pipelined(gpu):
         rb.free()
 
 
+def test_msm_batch_with_growing_jobs_in_a_reused_slot(gpu):
+    """A pipelined batch whose jobs GROW in the position that re-uses a buffer slot (job k + 2 after job k: the GM17 prover's
+    batch mixes key sizes): the pool replaces the slot's buffers while the job before may still be reducing out of them --
+    only after the device has drained (msm_impl.h issue_sort(k + 1) before finish(k - 1)).  Every sum of the batch
+    must equal the same MSM run alone."""
+    curve = "mnt4753_g1"
+    C = pyref.CURVES[curve]
+    sizes = [1 << 12, 1 << 12, 1 << 15, (1 << 15) + 777, 1 << 17, 1 << 13, (1 << 17) + 5]
+    nmax = max(sizes)
+    rb = gpu.ResidentBases.chain(curve, *S.bases_array(C, S.chain_points(C, 2, pyref.Rng(77)))[0], nmax)
+    keys = []
+    for i, n in enumerate(sizes):
+        pts = rb.download(0, n)
+        k = gpu.ResidentBases(curve, pts)
+        if i % 2 == 0:
+            k.precompute(0)
+        s = S.random_scalars_np(n, seed=500 + i, below=C.order)
+        keys.append((k, gpu.DeviceBuffer(n * 96).upload(s), n))
+    try:
+        gpu.dev_trim()                                               # empty pools: every larger job has to grow its slot
+        batch = gpu.msm_batch_dev(keys)
+        for (k, d, n), got in zip(keys, batch):
+            a, b = gpu.proj_to_affine(curve, got), gpu.proj_to_affine(curve, k.msm_dev(d, n))
+            assert a[1] == b[1] and (a[0] == b[0]).all(), n
+    finally:
+        for k, d, _ in keys:
+            k.free()
+            d.free()
+        rb.free()
+
+
 @pytest.mark.parametrize("curve,n,windows", [("mnt4753_g1", 3000, (0, 9, 13)), ("mnt6753_g1", 700, (0, 12)),
                                              ("mnt4753_g2", 640, (0, 9)), ("mnt6753_g2", 620, (0, 8))])
 def test_msm_affine_bucket_sums_vs_oracle(gpu, curve, n, windows):
