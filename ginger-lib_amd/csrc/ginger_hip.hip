@@ -334,6 +334,9 @@ int gh_bases_free(gh_bases_t handle) try {
     if (h->d_points) hipFree(h->d_points);
     if (h->d_inf) hipFree(h->d_inf);
     if (h->d_table) hipFree(h->d_table);
+    if (h->d_dup_starts) hipFree(h->d_dup_starts);
+    if (h->d_dup_members) hipFree(h->d_dup_members);
+    if (h->d_dup_chunks) hipFree(h->d_dup_chunks);
     h->magic = 0;
     delete h;
     return GH_OK;
@@ -578,13 +581,16 @@ KeyCache kc;
 size_t key_bytes(const BasesBase* h) {
     const int deg = h->curve == GH_MNT4753_G2 ? 2 : (h->curve == GH_MNT6753_G2 ? 3 : 1);
     const size_t pt = (size_t)208 * deg;
-    return h->n * pt + (h->d_inf ? h->n : 0) + (h->d_table ? (size_t)h->pre_W * h->n * pt : 0);
+    return h->n * pt + (h->d_inf ? h->n : 0) + (h->d_table ? (size_t)h->pre_W * h->n * pt : 0) + (size_t)4 * (h->n_dup_groups + 1 + h->n_dup_members);
 }
 void free_key(BasesBase* h) {
     if (!h) return;
     if (h->d_points) hipFree(h->d_points);
     if (h->d_inf) hipFree(h->d_inf);
     if (h->d_table) hipFree(h->d_table);
+    if (h->d_dup_starts) hipFree(h->d_dup_starts);
+    if (h->d_dup_members) hipFree(h->d_dup_members);
+    if (h->d_dup_chunks) hipFree(h->d_dup_chunks);
     h->magic = 0;
     delete h;
 }

@@ -8,6 +8,7 @@
 #include <vector>
 #include "runtime.h"
 #include "msm_kernels.h"
+#include <algorithm>
 #include "asm_kernels.h"
 #include "host_math.h"
 
@@ -163,6 +164,111 @@ inline int precompute_window(size_t n, int deg) {
     return c;
 }
 
+// Groups of equal bases (msm_kernels.h "equal bases"): hashed on the device, grouped on the host, verified limb for limb on the
+// device.  Optional: any failure leaves the key without groups (every base its own).  Called when the shift table is built --
+// a key that gets a table is a key that is used again.  GH_DEDUP=0 switches it off (A/B).
+template <class C>
+int dedup_bases(BasesBase* h) {
+    if (h->d_dup_starts) { (void)hipFree(h->d_dup_starts); h->d_dup_starts = nullptr; }
+    if (h->d_dup_members) { (void)hipFree(h->d_dup_members); h->d_dup_members = nullptr; }
+    if (h->d_dup_chunks) { (void)hipFree(h->d_dup_chunks); h->d_dup_chunks = nullptr; }
+    h->n_dup_groups = h->n_dup_members = h->n_dup_chunks = 0;
+    static const bool off = getenv("GH_DEDUP") && atoi(getenv("GH_DEDUP")) == 0;
+    const size_t n = h->n;
+    if (off || n < 2 || n >= ((size_t)1 << 31)) return GH_OK;
+    hipStream_t st = g.stream;
+    uint64_t* d_hash = nullptr;
+    int rc;
+    if ((rc = pool_get("dedup_hash", n * 16, (void**)&d_hash))) return rc;
+    GH_LAUNCH((msm_base_hash_kernel<C>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const Aff<C>*)h->d_points, (const uint8_t*)h->d_inf, n, d_hash);
+    std::vector<uint64_t> hh(2 * n);
+    HIPCHK(hipMemcpyAsync(hh.data(), d_hash, n * 16, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    // group by hash: indices sorted by (h1, h2, index); runs of equal hashes with at least two members are groups
+    std::vector<uint32_t> idx(n);
+    for (size_t i = 0; i < n; i++) idx[i] = (uint32_t)i;
+    std::sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) {
+        if (hh[2 * (size_t)a] != hh[2 * (size_t)b]) return hh[2 * (size_t)a] < hh[2 * (size_t)b];
+        if (hh[2 * (size_t)a + 1] != hh[2 * (size_t)b + 1]) return hh[2 * (size_t)a + 1] < hh[2 * (size_t)b + 1];
+        return a < b;
+    });
+    std::vector<uint32_t> starts, members;
+    for (size_t i = 0; i < n;) {
+        size_t j = i + 1;
+        const uint64_t a1 = hh[2 * (size_t)idx[i]], a2 = hh[2 * (size_t)idx[i] + 1];
+        while (j < n && hh[2 * (size_t)idx[j]] == a1 && hh[2 * (size_t)idx[j] + 1] == a2) j++;
+        if (j - i >= 2 && !(a1 == 0 && a2 == 0)) {            // (0, 0): infinity bases -- the digits stage skips them anyway
+            starts.push_back((uint32_t)members.size());
+            for (size_t k = i; k < j; k++) members.push_back(idx[k]);      // ascending: the canonical base is the smallest index
+        }
+        i = j;
+    }
+    if (starts.empty()) return GH_OK;
+    starts.push_back((uint32_t)members.size());
+    uint32_t *d_st = nullptr, *d_mem = nullptr;
+    uint8_t* d_flags = nullptr;
+    HIPCHK(hipMalloc((void**)&d_st, starts.size() * 4));
+    if (hipMalloc((void**)&d_mem, members.size() * 4) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(d_st); return GH_OK; }
+    if ((rc = pool_get("dedup_flags", members.size() + 16, (void**)&d_flags))) { (void)hipFree(d_st); (void)hipFree(d_mem); return GH_OK; }
+    const uint32_t ng = (uint32_t)starts.size() - 1;
+    hipError_t e = hipMemcpyAsync(d_st, starts.data(), starts.size() * 4, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_mem, members.data(), members.size() * 4, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemsetAsync(d_flags, 0, members.size(), st);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL((msm_dup_verify_kernel<C>), dim3(ng), dim3(256), 0, st, (const Aff<C>*)h->d_points, (const uint32_t*)d_st, ng, d_mem, d_flags);
+        e = hipGetLastError();
+    }
+    std::vector<uint8_t> flags(members.size());
+    if (e == hipSuccess) e = hipMemcpyAsync(flags.data(), d_flags, members.size(), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(members.data(), d_mem, members.size() * 4, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { (void)hipGetLastError(); (void)hipFree(d_st); (void)hipFree(d_mem); return GH_OK; }
+    bool collision = false;
+    for (uint8_t f : flags) collision |= f != 0;
+    if (collision) {      // equal 128-bit hashes over different abscissae: drop those members and rebuild the lists
+        std::vector<uint32_t> st2, mem2;
+        for (uint32_t gi = 0; gi < ng; gi++) {
+            const size_t b0 = mem2.size();
+            for (uint32_t j = starts[gi]; j < starts[gi + 1]; j++) if (!flags[j]) mem2.push_back(members[j]);
+            if (mem2.size() - b0 >= 2) st2.push_back((uint32_t)b0); else mem2.resize(b0);
+        }
+        (void)hipFree(d_st); (void)hipFree(d_mem);
+        if (st2.empty()) return GH_OK;
+        st2.push_back((uint32_t)mem2.size());
+        HIPCHK(hipMalloc((void**)&d_st, st2.size() * 4));
+        if (hipMalloc((void**)&d_mem, mem2.size() * 4) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(d_st); return GH_OK; }
+        HIPCHK(hipMemcpy(d_st, st2.data(), st2.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(d_mem, mem2.data(), mem2.size() * 4, hipMemcpyHostToDevice));
+        starts.swap(st2); members.swap(mem2);
+    }
+    // chunks of at most MSM_DUP_CHUNK members for the summation (msm_merge_scalars_kernel), then the chunk offsets per group
+    const uint32_t ngf = (uint32_t)starts.size() - 1;
+    std::vector<uint32_t> ch, goff(ngf + 1);
+    for (uint32_t gi = 0; gi < ngf; gi++) {
+        goff[gi] = (uint32_t)(ch.size() / 3);
+        for (uint32_t lo = starts[gi]; lo < starts[gi + 1]; lo += MSM_DUP_CHUNK) {
+            const uint32_t hi = starts[gi + 1] - lo > MSM_DUP_CHUNK ? lo + MSM_DUP_CHUNK : starts[gi + 1];
+            ch.push_back(lo); ch.push_back(hi); ch.push_back(gi);
+        }
+    }
+    goff[ngf] = (uint32_t)(ch.size() / 3);
+    const uint32_t nch = goff[ngf];
+    ch.insert(ch.end(), goff.begin(), goff.end());
+    uint32_t* d_ch = nullptr;
+    if (hipMalloc((void**)&d_ch, ch.size() * 4) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(d_st); (void)hipFree(d_mem); return GH_OK; }
+    if (hipMemcpy(d_ch, ch.data(), ch.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipGetLastError(); (void)hipFree(d_st); (void)hipFree(d_mem); (void)hipFree(d_ch);
+        return GH_OK;
+    }
+    h->d_dup_starts = d_st;
+    h->d_dup_members = d_mem;
+    h->d_dup_chunks = d_ch;
+    h->n_dup_groups = ngf;
+    h->n_dup_members = (uint32_t)members.size();
+    h->n_dup_chunks = nch;
+    return GH_OK;
+}
+
 template <class C>
 int precompute_bases(BasesBase* h, int c_req, int max_rows) {
     typedef typename C::FC::T FT;
@@ -253,6 +359,7 @@ int precompute_bases(BasesBase* h, int c_req, int max_rows) {
     h->pre_c = c;
     h->pre_W = W;
     h->pre_G = G;
+    (void)dedup_bases<C>(h);      // equal bases of the key: their scalars are added up before every MSM (optional: failures leave none)
     return GH_OK;
 }
 
@@ -552,6 +659,23 @@ struct MsmJob {
         HIPCHK(hipEventRecord(g.pev[es][0], st));
         HIPCHK(hipMemsetAsync(size_hist, 0, MSM_SIZE_BINS * 4, st));
         HIPCHK(hipMemsetAsync(plan, 0, 64, st));
+        if (h->n_dup_groups) {     // the scalars of equal bases, added up (msm_kernels.h "equal bases"): the MSM sees the distinct bases only
+            char nm[48];
+            uint32_t* merged_s = nullptr;
+            snprintf(nm, sizeof nm, "merged_scalars#%d", slot);
+            if ((rc = pool_get(nm, n * 96, (void**)&merged_s))) return rc;
+            HIPCHK(hipMemcpyAsync(merged_s, d_scalars, n * 96, hipMemcpyDeviceToDevice, st));
+            uint32_t* partial = nullptr;
+            snprintf(nm, sizeof nm, "merged_partial#%d", slot);
+            if ((rc = pool_get(nm, (size_t)h->n_dup_chunks * 96 + 96, (void**)&partial))) return rc;
+            GH_LAUNCH(msm_merge_scalars_kernel, dim3(h->n_dup_chunks), dim3(256), 0, st, (const uint32_t*)d_scalars, merged_s, n,
+                      (const uint32_t*)h->d_dup_starts, (const uint32_t*)h->d_dup_members, (const uint32_t*)h->d_dup_chunks, h->n_dup_chunks,
+                      partial, scalar_modulus<C>());
+            GH_LAUNCH(msm_merge_groups_kernel, dim3((h->n_dup_groups + 63) / 64), dim3(64), 0, st, merged_s, n, (const uint32_t*)h->d_dup_starts,
+                      (const uint32_t*)h->d_dup_members, (const uint32_t*)(h->d_dup_chunks + 3 * (size_t)h->n_dup_chunks), h->n_dup_groups,
+                      (const uint32_t*)partial, scalar_modulus<C>());
+            d_scalars = merged_s;
+        }
         // Bucket lists.  Large inputs: two-level counting sort with LDS atomics only (msm_kernels.h 2a); small ones: histogram +
         // scatter with device-scope atomics (fewer launches).  GH_SORT=atomic / part forces one of them where it applies.
         const size_t entries = (size_t)W * n;

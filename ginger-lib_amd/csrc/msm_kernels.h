@@ -312,6 +312,148 @@ static __device__ __forceinline__ uint32_t wave_agg_inc(uint32_t* base, uint32_t
 //     slot offset 2^(c-1): the host adds 2^(c-1) * sum(region b), msm_impl.h fold_windows).
 struct MsmModulus { uint32_t w[24]; };
 
+// ---- equal bases.  A proving key holds the SAME point for every variable with the same polynomial (the `Benchmark` circuit's
+// closing constraint puts L_last(t) into B for every recorded variable: half of b_query is one point), and
+// sum s_i P = (sum s_i) P: the scalars of equal (or opposite) bases are added up front and the MSM runs on the distinct bases only
+// (nothing in the reference does this; VariableBaseMSM::multi_scalar_mul's result is the same group element).  Without it every
+// pair of equal bases that meet in a bucket is a doubling / a cancellation (swp.rs:492) -- millions per MSM on such a key.
+// msm_base_hash_kernel: 128 bits over the abscissa's limbs per base (0, 0 for infinity); the host groups equal hashes
+// (msm_impl.h dedup_bases); msm_dup_verify_kernel compares every member with its group's first base limb for limb (a hash
+// collision drops out of the group) and records the sign; msm_merge_scalars_kernel does the sums at MSM time.
+template <class C>
+static __global__ void __launch_bounds__(256)
+msm_base_hash_kernel(const Aff<C>* __restrict__ pts, const uint8_t* __restrict__ inf, size_t n, uint64_t* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t h1 = 0x9E3779B97F4A7C15ull, h2 = 0xC2B2AE3D27D4EB4Full;
+    if (inf && inf[i]) { out[2 * i] = 0; out[2 * i + 1] = 0; return; }
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(&pts[i].x);
+    constexpr int NW = (int)(sizeof(pts[0].x) / 4);
+    for (int k = 0; k < NW; k++) {
+        const uint64_t x = w[k];
+        h1 = ((h1 ^ x) * 0xFF51AFD7ED558CCDull); h1 ^= h1 >> 29;
+        h2 = (h2 + x) * 0x94D049BB133111EBull; h2 = (h2 << 27) | (h2 >> 37);
+    }
+    if (h1 == 0 && h2 == 0) h1 = 1;
+    out[2 * i] = h1; out[2 * i + 1] = h2;
+}
+
+// members[j]: base index (bit 31 clear); group g = members[starts[g] .. starts[g + 1]), its first entry the canonical base.
+// Sets bit 31 where the member is the NEGATIVE of the canonical base; flags[j] = 1 where it is neither (not the same point).
+template <class C>
+static __global__ void __launch_bounds__(256)
+msm_dup_verify_kernel(const Aff<C>* __restrict__ pts, const uint32_t* __restrict__ starts, uint32_t n_groups, uint32_t* __restrict__ members,
+                      uint8_t* __restrict__ flags) {
+    const uint32_t g = blockIdx.x;
+    if (g >= n_groups) return;
+    const uint32_t lo = starts[g], hi = starts[g + 1];
+    const uint32_t canon = members[lo] & 0x7FFFFFFFu;
+    constexpr int NW = (int)(sizeof(pts[0].x) / 4);
+    const uint32_t* cx = reinterpret_cast<const uint32_t*>(&pts[canon].x);
+    const uint32_t* cy = reinterpret_cast<const uint32_t*>(&pts[canon].y);
+    for (uint32_t j = lo + 1 + threadIdx.x; j < hi; j += blockDim.x) {
+        const uint32_t m = members[j] & 0x7FFFFFFFu;
+        const uint32_t* mx = reinterpret_cast<const uint32_t*>(&pts[m].x);
+        const uint32_t* my = reinterpret_cast<const uint32_t*>(&pts[m].y);
+        bool same_x = true, same_y = true;
+        for (int k = 0; k < NW; k++) { same_x &= mx[k] == cx[k]; same_y &= my[k] == cy[k]; }
+        // equal x on the curve: y equal or opposite (y = 0 would be both: a point of order two never enters a key)
+        flags[j] = same_x ? 0 : 1;
+        members[j] = m | ((same_x && !same_y) ? 0x80000000u : 0u);
+    }
+}
+
+// out = in with, per group, the canonical base's scalar replaced by the signed sum of the group's scalars mod r and the other
+// members' scalars zeroed.  One block per group; scalars are canonical integers below r (12 x u64 as 24 words).
+static __device__ __forceinline__ void scalar_add_mod(uint32_t* a, const uint32_t* b, const MsmModulus& r) {
+    uint32_t cy = 0;
+    uint32_t t[24];
+#pragma unroll
+    for (int k = 0; k < 24; k++) { const uint64_t x = (uint64_t)a[k] + b[k] + cy; a[k] = (uint32_t)x; cy = (uint32_t)(x >> 32); }
+    uint32_t bw = 0;
+#pragma unroll
+    for (int k = 0; k < 24; k++) { const uint64_t x = (uint64_t)a[k] - r.w[k] - bw; t[k] = (uint32_t)x; bw = (uint32_t)(x >> 32) & 1u; }
+    if (cy || !bw) {
+#pragma unroll
+        for (int k = 0; k < 24; k++) a[k] = t[k];
+    }
+}
+// Two steps, so that one huge group (half a proving key's b_query can be ONE point) is not one block's work: the groups are cut
+// into chunks of at most MSM_DUP_CHUNK members (chunks[3 k] = first member, [3 k + 1] = end, [3 k + 2] = group); step 1 sums a
+// chunk's scalars into partial[k] and zeroes its non-canonical members in `out`, step 2 adds a group's partial sums into its
+// canonical base's scalar.
+constexpr uint32_t MSM_DUP_CHUNK = 4096;
+static __global__ void __launch_bounds__(256)
+msm_merge_scalars_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, size_t n, const uint32_t* __restrict__ starts,
+                         const uint32_t* __restrict__ members, const uint32_t* __restrict__ chunks, uint32_t n_chunks,
+                         uint32_t* __restrict__ partial, MsmModulus r) {
+    __shared__ uint32_t part[256][25];
+    const uint32_t ck = blockIdx.x;
+    if (ck >= n_chunks) return;
+    const uint32_t lo = chunks[3 * ck], hi = chunks[3 * ck + 1], first = starts[chunks[3 * ck + 2]];
+    uint32_t acc[24];
+#pragma unroll
+    for (int k = 0; k < 24; k++) acc[k] = 0;
+    for (uint32_t j = lo + threadIdx.x; j < hi; j += blockDim.x) {
+        const uint32_t e = members[j], m = e & 0x7FFFFFFFu;
+        if (m >= n) continue;                                      // the call uses fewer scalars than the key has bases
+        uint32_t s[24];
+        const uint4* q = reinterpret_cast<const uint4*>(in + (size_t)m * 24);
+#pragma unroll
+        for (int k = 0; k < 6; k++) { const uint4 v = q[k]; s[4 * k] = v.x; s[4 * k + 1] = v.y; s[4 * k + 2] = v.z; s[4 * k + 3] = v.w; }
+        if (e >> 31) {                                             // - s = r - s (0 stays 0)
+            uint32_t any = 0, bw = 0;
+#pragma unroll
+            for (int k = 0; k < 24; k++) any |= s[k];
+            if (any) {
+#pragma unroll
+                for (int k = 0; k < 24; k++) { const uint64_t x = (uint64_t)r.w[k] - s[k] - bw; s[k] = (uint32_t)x; bw = (uint32_t)(x >> 32) & 1u; }
+            }
+        }
+        scalar_add_mod(acc, s, r);
+        if (j != first) {
+            uint4* o = reinterpret_cast<uint4*>(out + (size_t)m * 24);
+#pragma unroll
+            for (int k = 0; k < 6; k++) o[k] = make_uint4(0, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 24; k++) part[threadIdx.x][k] = acc[k];
+    __syncthreads();
+    for (uint32_t step = 128; step > 0; step >>= 1) {
+        if (threadIdx.x < step) {
+            uint32_t a[24], b[24];
+#pragma unroll
+            for (int k = 0; k < 24; k++) { a[k] = part[threadIdx.x][k]; b[k] = part[threadIdx.x + step][k]; }
+            scalar_add_mod(a, b, r);
+#pragma unroll
+            for (int k = 0; k < 24; k++) part[threadIdx.x][k] = a[k];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < 24) partial[(size_t)ck * 24 + threadIdx.x] = part[0][threadIdx.x];
+}
+// gchunk[g] .. gchunk[g + 1]: the chunks of group g (consecutive)
+static __global__ void __launch_bounds__(64)
+msm_merge_groups_kernel(uint32_t* __restrict__ out, size_t n, const uint32_t* __restrict__ starts, const uint32_t* __restrict__ members,
+                        const uint32_t* __restrict__ gchunk, uint32_t n_groups, const uint32_t* __restrict__ partial, MsmModulus r) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_groups) return;
+    const uint32_t canon = members[starts[g]] & 0x7FFFFFFFu;
+    if (canon >= n) return;                                        // members ascend: none of the group is in this call
+    uint32_t acc[24];
+#pragma unroll
+    for (int k = 0; k < 24; k++) acc[k] = 0;
+    for (uint32_t ck = gchunk[g]; ck < gchunk[g + 1]; ck++) {
+        uint32_t s[24];
+#pragma unroll
+        for (int k = 0; k < 24; k++) s[k] = partial[(size_t)ck * 24 + k];
+        scalar_add_mod(acc, s, r);
+    }
+#pragma unroll
+    for (int k = 0; k < 24; k++) out[(size_t)canon * 24 + k] = acc[k];
+}
+
 static __global__ void __launch_bounds__(256)
 msm_digits_kernel(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ infinity, size_t n, int c,
                   int num_windows, uint32_t win_stride, int top_unsigned, MsmModulus r,

@@ -101,6 +101,11 @@ struct BasesBase {
     int pre_c = 0, pre_W = 0;   // window bits, rows of the table
     int pre_G = 1;              // bucket sets: row j = 2^(pre_c pre_G j) P, window w = j pre_G + g reads row j and files into set g
                                 // (1 = full table, one bucket set; GH_TABLE_ROWS caps the rows: a partial table)
+    // equal bases (msm_kernels.h "equal bases"): groups of indices that hold the same point up to sign, found when the shift table is built
+    uint32_t* d_dup_starts = nullptr;   // n_dup_groups + 1
+    uint32_t* d_dup_members = nullptr;  // base index | negative << 31, the canonical base first
+    uint32_t* d_dup_chunks = nullptr;   // 3 per chunk (first member, end, group) followed by n_dup_groups + 1 chunk offsets per group
+    uint32_t n_dup_groups = 0, n_dup_members = 0, n_dup_chunks = 0;
     uint8_t aff_asm_off = 0;    // G2: an MSM over this key overflowed the exception list of the assembly rounds (a key with many equal
                                 // bases, e.g. a proving key's b_g2_query under an assignment with equal values: every pair of such bases
                                 // in a bucket is a doubling) -- later MSMs go straight to the C++ round kernel, which doubles inline

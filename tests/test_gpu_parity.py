@@ -585,6 +585,45 @@ def test_msm_affine_degenerate_inputs(gpu, curve):
         gpu.msm_set_affine(2)
 
 
+@pytest.mark.parametrize("curve", ["mnt4753_g1", "mnt4753_g2", "mnt6753_g2"])
+def test_msm_adds_up_the_scalars_of_equal_bases(gpu, curve):
+    """A key with a shift table knows its equal bases (msm_impl.h dedup_bases: hashed on the device, grouped on the host,
+    verified limb for limb) and adds their scalars up before the MSM: sum s_i P = (sum s_i) P, opposite bases with the
+    opposite sign.  One large group (every third base the same point, as a proving key's b_query has for the variables of a
+    closing constraint), pairs of equal and of opposite bases, an infinity base, scalars 0 / 1 / r - 1 inside groups, fewer
+    scalars than bases -- against the oracle's plain multi_scalar_mul (variable_base.rs:10-83), table path and batch."""
+    C = pyref.CURVES[curve]
+    r = C.order
+    n = 3000
+    rng = pyref.Rng(88)
+    pool = S.chain_points(C, n, rng)
+    pts = list(pool)
+    for i in range(0, n, 3):
+        pts[i] = pool[0]                                   # one big group
+    for i in range(1, 600, 6):
+        pts[i + 3] = pts[i]                                # pairs P, P
+        pts[i + 4] = C.neg(pts[i + 1])                     # pairs Q, -Q (i + 1 is not a multiple of 3 here: i = 1 mod 6)
+    pts[7] = None
+    scal = [rng.field_elem(r) for _ in range(n)]
+    scal[0], scal[3], scal[6], scal[9] = 0, 1, r - 1, (r + 1) // 2
+    scal[1], scal[4] = r - 5, 5                            # a pair whose scalars cancel
+    b, inf = S.bases_array(C, pts)
+    s = S.scalar_array(scal)
+    rb = gpu.ResidentBases(curve, b, inf)
+    try:
+        rb.precompute(7)
+        for m in (n, n - 1000, 5):
+            exp = S.oracle_msm(curve, b[:m], inf[:m], s[:m], 8)
+            assert affine_eq(gpu, curve, rb.msm(s[:m]), exp), m
+        d = gpu.DeviceBuffer(n * 96).upload(s)
+        outs = gpu.msm_batch_dev([(rb, d, n), (rb, d, n - 1000), (rb, d, n)])
+        assert affine_eq(gpu, curve, outs[0], S.oracle_msm(curve, b, inf, s, 8)) and affine_eq(gpu, curve, outs[2], S.oracle_msm(curve, b, inf, s, 8))
+        assert affine_eq(gpu, curve, outs[1], S.oracle_msm(curve, b[:n - 1000], inf[:n - 1000], s[:n - 1000], 8))
+        d.free()
+    finally:
+        rb.free()
+
+
 @pytest.mark.parametrize("curve", ["mnt4753_g2", "mnt6753_g2"])
 def test_g2_key_of_duplicate_bases_leaves_the_assembly_rounds(gpu, curve):
     """A proving key's b_g2_query holds equal points wherever two variables have the same polynomial, and an assignment with
@@ -603,7 +642,8 @@ def test_g2_key_of_duplicate_bases_leaves_the_assembly_rounds(gpu, curve):
     rb = gpu.ResidentBases(curve, dup)
     gpu.msm_set_affine(1)
     try:
-        rb.precompute(0)
+        # (no shift table for the doubled key: building one would find the equal bases and add their scalars up front --
+        #  test_msm_adds_up_the_scalars_of_equal_bases -- and no doubling would be left for the rounds)
         rb_half.precompute(0)
         ref = gpu.proj_add(curve, rb_half.msm(s_half), rb_half.msm(s_half))
         e_xy, e_inf = gpu.proj_to_affine(curve, ref)
