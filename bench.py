@@ -272,7 +272,8 @@ def main():
 
     # which accumulation the library's automatic policy picked for this curve (include/ginger_hip.h: gh_msm_set_affine)
     xyzz = C.deg == 1 and os.environ.get("GH_ACC_XYZZ", "1") != "0"
-    bucket_mode = "affine rounds (aff_kernels.h) + projective finish" if (C.deg > 1 and os.environ.get("GH_AFFINE", "2") != "0") or os.environ.get("GH_AFFINE") == "1" \
+    AFF_MODE = "affine rounds (asmgen/g2_rounds.py) + projective finish" if os.environ.get("GH_AFF_ASM", "1") != "0" else "affine rounds (aff_kernels.h) + projective finish"
+    bucket_mode = AFF_MODE if (C.deg > 1 and os.environ.get("GH_AFFINE", "2") != "0") or os.environ.get("GH_AFFINE") == "1" \
         else ("XYZZ mixed additions (madd-2008-s, 8 M + 2 S, Y3 as one dual product)" if xyzz else "projective mixed additions")
     if args.warmup:
         run_steps(args.warmup)
@@ -371,7 +372,7 @@ def main():
         "closed_form_ok": cf_ok,
         "closed_form_note": "each rank's partial sum of the last timed step == (sum s_i) P_0 + (sum i s_i) H on its chain key, evaluated with "
                             "Python integers (tests/support.py chain_msm_closed_form): an answer no MSM code path produced",
-        "roofline": {"kernel": "%s (bucket accumulation of the %s MSM)" % ("msm_accumulate_xyzz_kernel" if xyzz else "msm_accumulate_kernel / aff_round_kernel", curve), "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+        "roofline": {"kernel": "%s (bucket accumulation of the %s MSM)" % (("gh_asm_acc_g1 (generated assembly of msm_accumulate_xyzz_kernel)" if os.environ.get("GH_ACC_ASM", "1") != "0" else "msm_accumulate_xyzz_kernel") if xyzz else "msm_accumulate_kernel / aff_round_kernel", curve), "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_acc,
                      "traffic_note": "FETCH_SIZE + WRITE_SIZE bytes of the accumulation launches of one MSM from %s (separate rocprofv3 --pmc passes), null when that file was measured on other kernel sources (sha256 of ginger-lib_amd/csrc) or another workload; measured by the builder: %s" % (traffic_src, traffic_when or "box and date unknown"),
                      "avg_launch_ms": acc_avg_ms, "algorithmic_bytes_per_launch": alg_bytes,
@@ -548,7 +549,7 @@ def main():
                 out["g2"][crv] = {"workload": "%s VariableBaseMSM, 2^%d pairs, resident key with shift table" % (crv, lg),
                                   "steps_per_figure": KG,
                                   "closed_form_ok": closed_form_ok(crv, p0g, stg, sg, g_out) and closed_form_ok(crv, p0g, stg, sg, gb_out[-1]),
-                                  "roofline": {"kernel": "aff_round_kernel + projective finish (all accumulation launches of one MSM)", "bound": "hbm",
+                                  "roofline": {"kernel": "gh_asm_aff_* round kernels + inversion + projective finish (all accumulation launches of one MSM)", "bound": "hbm",
                                                "achieved": g_bytes / (gtm["accumulate_ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                                "frac": g_bytes / (gtm["accumulate_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic_g2.get(crv),
                                                "avg_launch_ms": gtm["accumulate_ms"], "algorithmic_bytes_per_launch": g_bytes},
@@ -556,7 +557,7 @@ def main():
                                            "peak_fpmul_per_s": FPMUL_PEAK_PER_S, "fp_products_per_addition": g_per_add,
                                            "frac": gtm["accumulate_madds"] * g_per_add / (gtm["accumulate_ms"] * 1e-3) / FPMUL_PEAK_PER_S},
                                   "value": ng / bt_ms * 1e3, "unit": "scalar-muls/s", "ms_per_msm_pipelined": bt_ms, "single_msm_ms": one_ms,
-                                  "window_bits": cg, "table_build_s": build_s, "bucket_sums": "affine rounds (aff_kernels.h) + projective finish" if os.environ.get("GH_AFFINE", "2") != "0" else "projective mixed additions",
+                                  "window_bits": cg, "table_build_s": build_s, "bucket_sums": AFF_MODE if os.environ.get("GH_AFFINE", "2") != "0" else "projective mixed additions",
                                   "phases_ms": {k: gtm[k] for k in ("sort_ms", "accumulate_ms", "reduce_ms", "fold_ms") if k in gtm}}
                 if not out["g2"][crv]["closed_form_ok"]:
                     out["error"] = "%s: result differs from the closed form" % crv

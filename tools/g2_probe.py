@@ -1,4 +1,4 @@
-"""MSMs over a chain key (distinct bases, as bench.py's) for profiling: python3 tools/g2_probe.py <curve> <log_n> [reps=2] [window]"""
+"""MSMs over a chain key (distinct bases, as bench.py's; any of the four curves) for profiling: python3 tools/g2_probe.py <curve> <log_n> [reps=2] [window]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -12,7 +12,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from bench import kernels_sha
 
-ACC = ("msm_accumulate_kernel", "msm_accumulate_xyzz_kernel", "msm_accumulate_split_kernel", "aff_round_kernel", "aff_desc_kernel", "msm_heavy_combine_kernel")
+ACC = ("msm_accumulate_kernel", "msm_accumulate_xyzz_kernel", "msm_accumulate_split_kernel", "aff_round_kernel", "aff_desc_kernel", "msm_heavy_combine_kernel",
+       "gh_asm_acc_g1", "gh_asm_aff", "aff_inv_kernel", "aff_fix_kernel", "msm_acc_tasks_kernel")
 
 
 def per_dispatch(path, counter):
@@ -44,7 +45,9 @@ def main():
     out_path = sys.argv[1]
     out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes); bytes = counter (KB) * 1024; "
                      "MI355X_MICROARCH.md: FETCH_SIZE reports half the bytes of wide coalesced streaming reads -- raw figures given",
-           "kernels_sha256": kernels_sha()}
+           "kernels_sha256": kernels_sha(),
+           "measured": "by the builder through gpurun on %s (UTC), MI355X box %s" % (__import__("time").strftime("%Y-%m-%d %H:%M", __import__("time").gmtime()),
+                                                                                    __import__("socket").gethostname())}
     for spec in sys.argv[2:]:
         key, fetch, write, wbits, mode = spec.split(":", 4)
         if key.startswith("ntt"):

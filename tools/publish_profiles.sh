@@ -6,9 +6,9 @@ SRC=$1; R=$2
 cp "$SRC/stats/run_kernel_stats.csv" "profiles/${R}_rocprofv3_kernel_stats_bench.csv"
 cp "$SRC/pmc_traffic.json" "profiles/${R}_pmc_traffic.json"
 for k in g1 g2 g2m6 ntt; do for c in FETCH_SIZE WRITE_SIZE; do
-  python3 tools/pmc_table.py "$SRC/${k}_$c/run_counter_collection.csv" msm_accumulate aff_round ntt_ > "profiles/${R}_pmc_${k}_$c.txt"
+  python3 tools/pmc_table.py "$SRC/${k}_$c/run_counter_collection.csv" msm_accumulate aff_round gh_asm aff_inv ntt_ > "profiles/${R}_pmc_${k}_$c.txt"
 done; done
 for k in g1 g2 g2m6; do
-  [ -f "$SRC/sq_$k/run_counter_collection.csv" ] && python3 tools/pmc_table.py "$SRC/sq_$k/run_counter_collection.csv" msm_accumulate aff_round msm_wave_reduce > "profiles/${R}_sq_$k.txt"
+  [ -f "$SRC/sq_$k/run_counter_collection.csv" ] && python3 tools/pmc_table.py "$SRC/sq_$k/run_counter_collection.csv" msm_accumulate aff_round gh_asm msm_wave_reduce > "profiles/${R}_sq_$k.txt"
 done
 ls -la profiles | grep "${R}_"

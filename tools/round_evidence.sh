@@ -6,7 +6,7 @@
 # 3. the default bench line, twice (plain `python bench.py` = the driver's command), and the two-rank rehearsals on one card
 set -o pipefail
 OUT=${1:-gpurun_out/evidence}
-R=${2:-r03}
+R=${2:-r04}
 mkdir -p "$OUT"
 bash tools/collect_profiles.sh "$OUT/prof" > "$OUT/collect.log" 2>&1 || { echo "collect_profiles failed"; tail -5 "$OUT/collect.log"; exit 1; }
 cp "$OUT/prof/pmc_traffic.json" "profiles/${R}_pmc_traffic.json"
