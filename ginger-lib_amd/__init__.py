@@ -33,7 +33,7 @@ ABI_SYMBOLS = [
     "gh_msm_resident", "gh_msm_resident_dev", "gh_msm_resident_dev_batch",
     "gh_msm_cached", "gh_key_cache_config", "gh_key_cache_clear", "gh_key_cache_stats", "gh_bases_content_hash",
     "gh_bases_key_id", "gh_test_hooks",
-    "gh_msm_set_window", "gh_msm_set_affine", "gh_msm_get_window", "gh_msm_last_timing", "gh_msm_batch_timing",
+    "gh_msm_set_window", "gh_msm_set_affine", "gh_msm_set_dedup", "gh_msm_get_window", "gh_msm_last_timing", "gh_msm_batch_timing",
     "gh_domain_supported", "gh_fft", "gh_fft_dev", "gh_vec_mul_dev", "gh_vec_sub_dev", "gh_vec_scale_dev",
     "gh_vec_mul", "gh_vec_scale", "gh_fft_last_kernel_ms", "gh_measure_fpmul_peak", "gh_kernel_resources", "gh_witness_map", "gh_witness_map_dev",
     "gh_sap_witness_map", "gh_sap_witness_map_dev", "gh_batch_inverse", "gh_batch_inverse_dev",
@@ -107,6 +107,7 @@ def load_library():
     lib.gh_test_hooks.argtypes = [ci]
     lib.gh_msm_set_window.argtypes = [ci]
     lib.gh_msm_set_affine.argtypes = [ci]
+    lib.gh_msm_set_dedup.argtypes = [ci]
     lib.gh_msm_get_window.argtypes = [ci, sz]
     lib.gh_msm_last_timing.argtypes = [ctypes.POINTER(MsmTiming)]
     lib.gh_msm_batch_timing.argtypes = [ci, ctypes.POINTER(MsmTiming)]
@@ -433,6 +434,11 @@ def msm_set_window(c):
 def msm_set_affine(mode):
     """0: projective bucket sums, 1: affine rounds always, 2: automatic (default)."""
     _check(load_library().gh_msm_set_affine(int(mode)))
+
+
+def msm_set_dedup(on):
+    """gh_msm_set_dedup: add up the scalars of a key's equal bases before its MSMs (tables built from now on); default on"""
+    _check(load_library().gh_msm_set_dedup(1 if on else 0))
 
 
 def dev_trim():

@@ -772,6 +772,11 @@ int gh_msm_set_affine(int on) try {
     g.affine_mode = on;
     return GH_OK;
 } catch (...) { return gh_rt::api_exception(); }
+int gh_msm_set_dedup(int on) try {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g.dedup_mode = on ? 1 : 0;
+    return GH_OK;
+} catch (...) { return gh_rt::api_exception(); }
 int gh_msm_get_window(gh_curve_t curve, size_t n) try {
     std::lock_guard<std::mutex> lk(g_mu);
     return auto_window(n, curve == GH_MNT4753_G2 ? 2 : (curve == GH_MNT6753_G2 ? 3 : 1));

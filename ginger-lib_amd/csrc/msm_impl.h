@@ -175,7 +175,7 @@ int dedup_bases(BasesBase* h) {
     h->n_dup_groups = h->n_dup_members = h->n_dup_chunks = 0;
     static const bool off = getenv("GH_DEDUP") && atoi(getenv("GH_DEDUP")) == 0;
     const size_t n = h->n;
-    if (off || n < 2 || n >= ((size_t)1 << 31)) return GH_OK;
+    if (off || !g.dedup_mode || n < 2 || n >= ((size_t)1 << 31)) return GH_OK;
     hipStream_t st = g.stream;
     uint64_t* d_hash = nullptr;
     int rc;

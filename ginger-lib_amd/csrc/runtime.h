@@ -44,6 +44,7 @@ struct Ctx {
     gh_msm_timing_t last_msm{};
     std::vector<gh_msm_timing_t> batch_tm;   // per-MSM timings of the last batch call
     float last_fft_ms = 0;
+    int dedup_mode = 1;                 // gh_msm_set_dedup: add up the scalars of equal bases (keys with a shift table)
     size_t scratch_reserved = 0;        // scratch_guard(): stack-frame scratch the runtime already holds for this context's queues
     std::vector<std::function<void()>> at_shutdown;   // releases of function-local device / pinned allocations
 };

@@ -197,6 +197,11 @@ int gh_fixed_base_free(gh_fixed_table_t table);
 
 /* Window size override for sweeps (0 = automatic).  Affects subsequent MSM calls. */
 int gh_msm_set_window(int c);
+/* Equal bases of a key (a proving key holds the same point for every variable with the same polynomial) are found when the
+ * key's shift table is built and their scalars are added up before every MSM over it (sum s_i P = (sum s_i) P: the result is
+ * the same group element).  0 switches that off for tables built afterwards (tests that want the bucket paths under many
+ * equal bases; A/B runs); default 1. */
+int gh_msm_set_dedup(int on);
 int gh_msm_get_window(gh_curve_t curve, size_t n);
 /* Bucket sums in AFFINE coordinates: pairwise rounds over the flat bucket-ordered list, the inversions of a
  * lane's whole batch shared by Montgomery's trick (5 M + 1 S + a share of one safegcd inversion per addition

@@ -25,3 +25,12 @@ def gl():
 def gpu(gl):
     gl.init()   # raises GingerHipError without a gfx950 device: GPU tests must not silently pass
     return gl
+
+
+@pytest.fixture
+def no_dedup(gpu):
+    """Tests whose keys are a small pool of points tiled to a large size (so that the oracle can referee, or to fill buckets with
+    equal and opposite bases on purpose) switch the adding-up of equal bases off: they are about the bucket paths at that size."""
+    gpu.msm_set_dedup(0)
+    yield
+    gpu.msm_set_dedup(1)

@@ -57,7 +57,7 @@ def skew(s, r):
 
 
 # ------------------------------------------------------------------------------ config 3 at 2^24
-def test_cfg3_mnt4_g1_2p24(gpu):
+def test_cfg3_mnt4_g1_2p24(gpu, no_dedup):
     curve = "mnt4753_g1"
     C = pyref.CURVES[curve]
     r = C.order
@@ -151,7 +151,7 @@ def test_full_size_msm_against_closed_form(gpu, curve, log_n, with_table):
 @pytest.mark.parametrize("curve,log_n,pool_n,with_table", [("mnt6753_g1", 19, 4096, True), ("mnt6753_g1", 22, 4096, True),
                                                           ("mnt6753_g2", 19, 512, True), ("mnt6753_g2", 22, 512, False),
                                                           ("mnt4753_g2", 20, 512, True)])
-def test_cfg4_shapes(gpu, curve, log_n, pool_n, with_table):
+def test_cfg4_shapes(gpu, no_dedup, curve, log_n, pool_n, with_table):
     C = pyref.CURVES[curve]
     r = C.order
     n = 1 << log_n
@@ -182,7 +182,7 @@ def test_cfg4_shapes(gpu, curve, log_n, pool_n, with_table):
 
 
 @pytest.mark.parametrize("curve,log_n", [("mnt4753_g2", 15), ("mnt6753_g2", 14), ("mnt6753_g1", 16)])
-def test_split_kernels_heavy_buckets_batch_vs_oracle(gpu, curve, log_n):
+def test_split_kernels_heavy_buckets_batch_vs_oracle(gpu, no_dedup, curve, log_n):
     """mid-size oracle parity with skewed scalars (heavy buckets and chunks), duplicate and opposite bases, with and
     without the shift table (several pseudo-windows, L1 = 16 segments), and as a pipelined batch of 4 MSMs"""
     C = pyref.CURVES[curve]
@@ -221,7 +221,7 @@ def test_split_kernels_heavy_buckets_batch_vs_oracle(gpu, curve, log_n):
         gpu.dev_trim()
 
 
-def test_partition_sort_path_skewed_vs_oracle(gpu):
+def test_partition_sort_path_skewed_vs_oracle(gpu, no_dedup):
     """the bucket lists of large inputs come from the two-level counting sort (msm_kernels.h 2a: W n >= 2^22 entries): oracle parity
     at 2^17 pairs with skewed scalars (zeros, ones, one value repeated thousands of times: heavy buckets, bins with a single
     bucket holding most entries), infinity bases, per-window path and shift table, one MSM and a batch with a ragged length"""
@@ -311,12 +311,12 @@ def _replay(gpu, log_n, with_oracle):
     gpu.dev_trim()
 
 
-def test_cfg5_replay_2p16_vs_oracle(gpu):
+def test_cfg5_replay_2p16_vs_oracle(gpu, no_dedup):
     """witness map + into_repr + MSM stage at 2^16 constraints against the oracle's literal replay (nine MSMs)"""
     _replay(gpu, 16, True)
 
 
-def test_cfg5_replay_2p20(gpu):
+def test_cfg5_replay_2p20(gpu, no_dedup):
     """the same at BASELINE config 5's size: A, B, C from the table path and from the per-window path agree"""
     _replay(gpu, 20, False)
 

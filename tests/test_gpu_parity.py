@@ -262,7 +262,7 @@ def test_msm_skewed_scalars(gpu):
     assert affine_eq(gpu, curve, got, S.oracle_msm(curve, b, inf, s, 16))
 
 
-def test_msm_full_size_properties(gpu):
+def test_msm_full_size_properties(gpu, no_dedup):
     """BASELINE config 3 size (2^20 pairs): linearity msm(s) + msm(t) == msm(s + t mod r) and
     invariance of the affine result under the window size; spot check vs the oracle at 2^14."""
     curve = "mnt4753_g1"
@@ -329,7 +329,7 @@ def test_msm_full_size_properties(gpu):
 # ------------------------------------------------------------------------------ MSM on a precomputed shift table
 @pytest.mark.parametrize("curve,n,windows", [("mnt4753_g1", 300, (0, 4, 7, 13, 16, 17, 19)), ("mnt6753_g1", 200, (0, 11, 18)),
                                              ("mnt4753_g2", 90, (0, 9, 17)), ("mnt6753_g2", 60, (0, 12))])
-def test_msm_precomputed_vs_oracle(gpu, curve, n, windows):
+def test_msm_precomputed_vs_oracle(gpu, no_dedup, curve, n, windows):
     """gh_bases_precompute: every window files into one bucket set (table row w = 2^(c w) P).  Same
     affine result as the oracle for: c | 752 (carry-only top window), one and several pseudo-windows
     of the reduction (c <= 16 / c >= 17), shorter scalar vectors, infinity / duplicate / opposite bases,
@@ -363,7 +363,7 @@ def test_msm_precomputed_vs_oracle(gpu, curve, n, windows):
 
 
 @pytest.mark.parametrize("curve,n", [("mnt4753_g1", 400), ("mnt6753_g1", 150), ("mnt4753_g2", 80), ("mnt6753_g2", 50)])
-def test_msm_partial_table_vs_oracle(gpu, curve, n):
+def test_msm_partial_table_vs_oracle(gpu, no_dedup, curve, n):
     """gh_bases_precompute_rows: at most max_rows rows (row j = 2^(c G j) P, G = ceil(windows / max_rows) bucket sets; window
     w = j G + g reads row j and files into set g; the sets are folded with c doublings each).  Every (c, max_rows) below --
     one row (= the bases themselves: one bucket set per window, like the plain path), two rows, a row count that does not
@@ -401,7 +401,7 @@ def test_msm_partial_table_vs_oracle(gpu, curve, n):
         rb.free()
 
 
-def test_msm_precomputed_skewed_and_large(gpu):
+def test_msm_precomputed_skewed_and_large(gpu, no_dedup):
     """witness-like scalars (long buckets -> chunk path) on the merged bucket set, and a 2^16-pair run
     against the oracle (BASELINE config 1 size) with the automatic table window"""
     curve = "mnt4753_g1"
@@ -514,7 +514,7 @@ def test_msm_batch_with_growing_jobs_in_a_reused_slot(gpu):
 
 @pytest.mark.parametrize("curve,n,windows", [("mnt4753_g1", 3000, (0, 9, 13)), ("mnt6753_g1", 700, (0, 12)),
                                              ("mnt4753_g2", 640, (0, 9)), ("mnt6753_g2", 620, (0, 8))])
-def test_msm_affine_bucket_sums_vs_oracle(gpu, curve, n, windows):
+def test_msm_affine_bucket_sums_vs_oracle(gpu, no_dedup, curve, n, windows):
     """gh_msm_set_affine(1): bucket sums by affine rounds (aff_kernels.h: pairwise rounds over the flat list, batched
     safegcd inversion).  Duplicate and opposite bases in one bucket (doubling / cancellation handled in the round),
     sums that pass through infinity, buckets of every length (c = 9: hundreds of entries per bucket; many equal small
@@ -559,7 +559,7 @@ def test_msm_affine_bucket_sums_vs_oracle(gpu, curve, n, windows):
 
 
 @pytest.mark.parametrize("curve", ["mnt4753_g1", "mnt6753_g1", "mnt4753_g2", "mnt6753_g2"])
-def test_msm_affine_degenerate_inputs(gpu, curve):
+def test_msm_affine_degenerate_inputs(gpu, no_dedup, curve):
     """affine rounds on inputs made of the group law's special cases only: all bases equal (every addition of every
     round is a doubling), bases in opposite pairs with equal scalars (every bucket cancels to infinity), a single pair,
     all scalars zero"""

@@ -41,7 +41,7 @@ def test_every_c_function_is_declared_once_with_the_same_arity():
             n_r = 0 if not rust[name].strip() else rust[name].count(",") + 1
             assert n_c == n_r, (name, n_c, n_r)
             n_total += 1
-    assert n_total == len(rust) == 73
+    assert n_total == len(rust) == 74
 
 
 def test_constants_and_timing_struct_match_the_header():
