@@ -150,9 +150,13 @@ class FieldGen:
     def mul(self, ch, a, b, m, d, dst=None, reduce=True):
         """dst = a b 2^-754 mod p.  m: free slot (m digits, then the unreduced result); d: slot that is dead once the product's
         columns are done (typically a or b) for the conditional subtraction; dst: m (default) or d."""
+        if not reduce:
+            # the unreduced result (< a b / R + p: below 2 p if at most one operand is itself unreduced) straight into dst: an
+            # operand of later products only, each time paired with a fully reduced one
+            yield from self.mont_columns(ch, self.mul_terms(a, b), m, m if dst is None else dst)
+            return
         yield from self.mont_columns(ch, self.mul_terms(a, b), m)
-        if reduce:
-            yield from self.cond_sub(ch, m, d, m if dst is None else dst)
+        yield from self.cond_sub(ch, m, d, m if dst is None else dst)
 
     def sqr(self, ch, a, a2, m, dst=None):
         """dst = a^2 2^-754 mod p.  a2: free slot for the doubled operand (dead afterwards: used by the reduction)."""

@@ -142,6 +142,7 @@ def build(name, p, one_mont, prefetch=False, split=4):
     run(f.neg_sel(chA, E[3], V_TMP, S_NEGSEL))
     interleave(f.mul(chA, E[2], E[1], E[4], E[2]),                  # x = X ZZZ -> E4
                f.mul(chB, E[3], E[0], E[5], E[3]))                  # y = Y ZZ  -> E5
+    run(f.cond_sub(chA, E[0], E[6], E[0]))                          # ZZ, ZZZ leave the loop below 2 p: one of them reduced for z
     run(f.mul(chA, E[0], E[1], E[6], E[2]))                         # z = ZZ ZZZ -> E6
     g.s_mov_b64(S_SAVE, EXEC)
     g.s_and_b64(EXEC, EXEC, S_ZERO)
@@ -235,11 +236,11 @@ def build(name, p, one_mont, prefetch=False, split=4):
                f.sqr(chB, E[5], E[3], E[7]))                        # RR = W^2      -> E7
     park_put(PARK_RR, E[7])
     interleave(f.mul(chA, E[4], E[6], E[2], E[4], dst=E[4]),        # PPP = P PP    -> E4
-               f.mul(chB, E[0], E[6], E[3], E[0], dst=E[0]))        # ZZ3 = ZZ PP   -> E0
+               f.mul(chB, E[0], E[6], E[3], E[0], dst=E[0], reduce=False))   # ZZ3 = ZZ PP -> E0, below 2 p (see the epilogue)
     park_get(PARK_X, E[2])
     g.s_waitcnt(lgkmcnt=0)
     interleave(f.mul(chA, E[2], E[6], E[3], E[2], dst=E[2]),        # Q = X PP      -> E2
-               f.mul(chB, E[1], E[4], E[7], E[1], dst=E[1]))        # ZZZ3 = ZZZ PPP -> E1
+               f.mul(chB, E[1], E[4], E[7], E[1], dst=E[1], reduce=False))   # ZZZ3 = ZZZ PPP -> E1, below 2 p
     park_get(PARK_RR, E[3])
     g.s_waitcnt(lgkmcnt=0)
     run(f.sub(chA, E[3], E[4], E[3]))                               # X3 = RR - PPP - 2 Q -> E3
