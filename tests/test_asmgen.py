@@ -184,3 +184,63 @@ def test_generated_module_text_is_well_formed():
     for line in text.splitlines():
         if "ds_read_b32" in line or "ds_write_b32" in line:
             assert int(line.split("offset:")[1].split()[0]) < 65536
+
+
+def test_hazard_padding_finds_the_gfx950_cases_and_pads_them():
+    """isa.fix_hazards: the wait states gfx940 / gfx950 do not interlock (LLVM GCNHazardRecognizer::checkVALUHazards,
+    hasVDecCoExecHazard) -- VALU writes SGPR -> VALU reads it: 2; VALU writes VGPR -> v_readfirstlane reads it: 1.  The second one
+    was met on the card: a kernel read its wave index as 0."""
+    from asmgen.isa import hazard_scan, fix_hazards
+    g = Prog("h")
+    g.v_lshrrev_b32(V(15), 6, V(0))
+    g.v_readfirstlane_b32(S(3), V(15))                  # needs 1 wait state
+    g.v_cmp_eq_u32(S(96, 2), 0, V(4))
+    g.v_cndmask_b32(V(6), V(16), V(17), S(96, 2))       # needs 2
+    g.v_cmp_eq_u32(S(98, 2), 0, V(4))
+    g.v_mov_b32(V(20), 1)
+    g.v_cndmask_b32(V(7), V(16), V(17), S(98, 2))       # one instruction in between: 1 more
+    g.v_sub_co_u32(V(1), S(16, 2), V(2), V(3))
+    g.v_subb_co_u32(V(4), S(16, 2), V(5), V(6), S(16, 2))   # carry chain: 2
+    g.v_cmp_eq_u32(S(90, 2), 0, V(4))
+    g.s_and_b64(S(92, 2), S(90, 2), S(94, 2))           # SALU reads are interlocked: nothing
+    g.v_mov_b32(V(30), 2)
+    g.v_mov_b32(V(31), 3)
+    g.v_cndmask_b32(V(8), V(16), V(17), S(90, 2))       # two instructions in between: nothing
+    g.label("join")
+    g.v_cndmask_b32(V(9), V(16), V(17), S(80, 2))       # first instruction behind a label: the worst predecessor is assumed
+    g.s_endpgm()
+    found, _ = hazard_scan(g, False)
+    assert [(op, need) for _, op, need in found] == [("v_readfirstlane_b32", 1), ("v_cndmask_b32", 2), ("v_cndmask_b32", 1),
+                                                     ("v_subb_co_u32", 2), ("v_cndmask_b32", 2)]
+    n = fix_hazards(g)
+    assert n == 5 and hazard_scan(g, False)[0] == []
+    assert [i.args[0] for i in g.ins if i.op == "s_nop"] == [0, 1, 0, 1, 1]          # s_nop N = N + 1 wait states
+    # every shipped kernel is hazard-free after its own padding
+    from asmgen import build
+    for prog in build.programs():
+        assert hazard_scan(prog, False)[0] == [], prog.name
+
+
+def test_simulator_refuses_a_register_with_a_result_in_flight():
+    """sim.py: a register a load / ds instruction will write may not be touched before the s_waitcnt that covers it"""
+    mem = Memory()
+    a = mem.add("buf", np.arange(64, dtype=np.uint32))
+    def prog(wait):
+        g = Prog("w")
+        g.v_lshlrev_b32(V(1), 2, V(0))
+        g.global_load_dword(V(2), V(1), S(4, 2))
+        if wait:
+            g.s_waitcnt(vmcnt=0)
+        g.v_add_u32(V(3), 1, V(2))
+        g.s_endpgm()
+        return g
+    for wait in (True, False):
+        w = Wave(prog(wait), mem)
+        w.S[4], w.S[5] = a & 0xFFFFFFFF, a >> 32
+        w.V[0] = np.arange(64, dtype=np.uint32)
+        if wait:
+            w.run()
+            assert list(w.V[3]) == list(range(1, 65))
+        else:
+            with pytest.raises(RuntimeError, match="in flight"):
+                w.run()
