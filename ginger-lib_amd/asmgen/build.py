@@ -28,7 +28,9 @@ def programs():
     # the affine rounds of the G2 MSMs: forward / backward kernel of round 0 and of the later rounds, per tower
     c2 = g2_rounds.Cfg(2, 13, P4, R % P4)          # MNT4-753 G2: Fq2 = Fq[u] / (u^2 - 13)   (fields/mnt4753/fq2.rs:19)
     c3 = g2_rounds.Cfg(3, 11, P6, R % P6)          # MNT6-753 G2: Fq3 = Fq[u] / (u^3 - 11)   (fields/mnt6753/fq3.rs)
-    for tag, cfg in (("f2", c2), ("f3", c3)):
+    c1a = g2_rounds.Cfg(1, 1, P4, R % P4)           # MNT4-753 G1 / MNT6-753 G1: the same rounds with one lane per element
+    c1b = g2_rounds.Cfg(1, 1, P6, R % P6)
+    for tag, cfg in (("f2", c2), ("f3", c3), ("f1p4", c1a), ("f1p6", c1b)):
         for fwd in (True, False):
             for r0 in (True, False):
                 progs.append(g2_rounds.build("gh_asm_aff_%s_%s_%s" % (tag, "fwd" if fwd else "bwd", "r0" if r0 else "rn"), cfg, fwd, r0))

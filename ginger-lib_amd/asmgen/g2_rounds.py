@@ -73,7 +73,7 @@ E = [slot(i) for i in range(8)]      # v20 .. v227
 
 
 class Cfg:
-    def __init__(self, lanes, nr, p, one_mont):
+    def __init__(self, lanes, nr, p, one_mont):     # lanes: 1 (G1), 2 (Fq2 lane pairs), 3 (Fq3 lane triples)
         self.L = lanes
         self.NR = nr
         self.p = p
@@ -200,6 +200,8 @@ def build(name, cfg, fwd, r0, debug=False):
 
     def prep_a(a, a1, a2):
         """the rotated / non-residue-scaled copies of the left operand: a1 = K1 a_(j-1), a2 = K2 a_(j-2)"""
+        if L == 1:
+            return
         run(f.bperm(a1, V_AP, a))
         if L == 3:
             run(f.bperm(a2, V_AN, a))
@@ -210,14 +212,20 @@ def build(name, cfg, fwd, r0, debug=False):
             run(f.mul_small(chA, a1, V_K1, a1, S_INVC))
 
     def prep_b(b, bs):
-        """the coefficients of the right operand, broadcast over the lane group"""
+        """the coefficients of the right operand, broadcast over the lane group (G1: the operand itself, copied: the product's
+        result may take b's slot while bs[0] is still read)"""
+        if L == 1:
+            run(f.copy(bs[0], b))
+            return
         for i in range(L):
             run(f.bperm(bs[i], V_BC[i], b))
 
     def tower_mul(a, a1, a2, bs, m, dd):
         """m = a (x) b in the tower (this lane's coefficient); a1, a2 from prep_a, bs from prep_b (waited for here)"""
         g.s_waitcnt(lgkmcnt=0)
-        if L == 2:
+        if L == 1:
+            run(f.mul(chA, a, bs[0], m, dd))
+        elif L == 2:
             run(f.dual(chA, chB, a, bs[0], a1, bs[1], m, dd))
         else:
             run(f.triple(chA, chB, [(a, bs[0]), (a1, bs[1]), (a2, bs[2])], m, dd))
@@ -229,7 +237,10 @@ def build(name, cfg, fwd, r0, debug=False):
 
     def list_addr(idx, addr, addr_b, addr_c):
         """64-bit addresses of element idx (per lane) of the input list: + 0, + 4096, + 12288"""
-        if L == 2:
+        if L == 1:
+            g.v_lshrrev_b32(V_T2, 6, idx)
+            g.v_and_b32(V_T3, 63, idx)
+        elif L == 2:
             g.v_lshrrev_b32(V_T2, 5, idx)
             g.v_and_b32(V_T3, 31, idx)
         else:
@@ -264,14 +275,17 @@ def build(name, cfg, fwd, r0, debug=False):
         g.s_cmp_eq_u64(S_T0, 0)
         L_NOBAD = g.uniq("nobad")
         g.s_cbranch_scc1(L_NOBAD)
-        g.v_cndmask_b32(V_T0, 0, 1, S_T0)
-        for i in range(L):                                           # or over the lane group
-            g.ds_bpermute_b32(V(V_T1.idx + i), V_BC[i], V_T0)
-        g.s_waitcnt(lgkmcnt=0)
-        g.v_or_b32(V_T0, V_T1, V_T2)
-        if L == 3:
-            g.v_or_b32(V_T0, V_T0, V_T3)
-        g.v_cmp_ne_u32(S_FLAG, 0, V_T0)
+        if L == 1:
+            g.s_mov_b64(S_FLAG, S_T0)
+        else:
+            g.v_cndmask_b32(V_T0, 0, 1, S_T0)
+            for i in range(L):                                       # or over the lane group
+                g.ds_bpermute_b32(V(V_T1.idx + i), V_BC[i], V_T0)
+            g.s_waitcnt(lgkmcnt=0)
+            g.v_or_b32(V_T0, V_T1, V_T2)
+            if L == 3:
+                g.v_or_b32(V_T0, V_T0, V_T3)
+            g.v_cmp_ne_u32(S_FLAG, 0, V_T0)
         g.s_andn2_b64(S_PAIR, S_PAIR, S_FLAG)
         g.label(L_NOBAD)
 
@@ -290,7 +304,11 @@ def build(name, cfg, fwd, r0, debug=False):
     g.v_lshlrev_b32(V_LANE16, 4, V_T0)
     g.v_lshrrev_b32(V_T1, 6, V_TID)
     g.v_readfirstlane_b32(S_TMP, V_T1)                              # wave of the block
-    if L == 2:
+    if L == 1:                                                      # G1: one lane per element, no exchange
+        g.v_mov_b32(V_COMP, 0)
+        g.v_mov_b32(V_G, V_T0)
+        g.s_mov_b64(S_LIVE, -1)
+    elif L == 2:
         g.v_and_b32(V_COMP, 1, V_T0)
         g.v_lshrrev_b32(V_G, 1, V_T0)
         g.s_mov_b64(S_LIVE, -1)
@@ -448,7 +466,7 @@ def build(name, cfg, fwd, r0, debug=False):
     X1, X2 = E[1], E[6]
     # backward kernel on lane pairs: E4 and E7 are free until lambda is formed, so y1 and y2 travel with x1 and x2 (one exposed
     # memory latency less per element); lane triples need all eight slots for the two products in between
-    early_y = (not fwd) and L == 2
+    early_y = (not fwd) and L <= 2
     def r0_rows():
         """round 0: the two list entries of the element (V_E1, V_E2: row | sign << 31) and the addresses of this lane's coefficient in
         their table rows (V_ADDR1, V_ADDR2)"""

@@ -23,7 +23,7 @@ struct State {
     bool tried = false;
     hipModule_t mod = nullptr;
     hipFunction_t acc_g1[2] = {nullptr, nullptr};   // [0]: p4 (MNT4-753 G1), [1]: p6 (MNT6-753 G1)
-    hipFunction_t aff[2][2][2] = {};                // [tower - 2][fwd][r0]
+    hipFunction_t aff[4][2][2] = {};                // [kind: f2, f3, f1p4, f1p6][fwd][r0]
     hipFunction_t mb_mulpair = nullptr;
 };
 State s;
@@ -51,11 +51,12 @@ int load_locked() {
             return GH_E_HIP;
         }
     }
-    for (int t = 0; t < 2; t++)
+    static const char* kinds[4] = {"f2", "f3", "f1p4", "f1p6"};
+    for (int t = 0; t < 4; t++)
         for (int fw = 0; fw < 2; fw++)
             for (int r0 = 0; r0 < 2; r0++) {
                 char nm[64];
-                snprintf(nm, sizeof nm, "gh_asm_aff_f%d_%s_%s", t + 2, fw ? "fwd" : "bwd", r0 ? "r0" : "rn");
+                snprintf(nm, sizeof nm, "gh_asm_aff_%s_%s_%s", kinds[t], fw ? "fwd" : "bwd", r0 ? "r0" : "rn");
                 e = hipModuleGetFunction(&s.aff[t][fw][r0], m, nm);
                 if (e != hipSuccess) {
                     g_err = std::string("hipModuleGetFunction(") + nm + ") failed: " + hipGetErrorString(e);
@@ -106,9 +107,14 @@ bool aff_enabled() {
     return on;
 }
 
+bool aff_g1_enabled() {
+    static const bool on = !(getenv("GH_AFF_ASM_G1") && atoi(getenv("GH_AFF_ASM_G1")) == 0);
+    return on && aff_enabled();
+}
+
 int aff_launch(int tower, bool fwd, bool r0, const AffArgs& a, uint32_t waves, hipStream_t st) {
     if (waves == 0 || a.n_out == 0) return GH_OK;
-    if (tower != 2 && tower != 3) { g_err = "internal: aff_launch tower"; return GH_E_BAD_ARG; }
+    if (tower < 0 || tower > 3) { g_err = "internal: aff_launch kind"; return GH_E_BAD_ARG; }
     // what the kernels' 32-bit index arithmetic assumes (asmgen/g2_rounds.py): element indices times 4 and a wave's list span
     if ((waves & 3u) || a.n_out >= (1u << 30) || (uint64_t)a.B * 13312u >= (1ull << 32) || a.B == 0) {
         g_err = "internal: affine round outside the assembly kernels' index range";
@@ -118,7 +124,7 @@ int aff_launch(int tower, bool fwd, bool r0, const AffArgs& a, uint32_t waves, h
     AffArgs args = a;
     size_t size = sizeof args;
     void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
-    HIPCHK(hipModuleLaunchKernel(s.aff[tower - 2][fwd ? 1 : 0][r0 ? 1 : 0], waves / 4, 1, 1, 256, 1, 1, 0, st, nullptr, extra));
+    HIPCHK(hipModuleLaunchKernel(s.aff[tower][fwd ? 1 : 0][r0 ? 1 : 0], waves / 4, 1, 1, 256, 1, 1, 0, st, nullptr, extra));
     return GH_OK;
 }
 

@@ -941,7 +941,8 @@ struct MsmJob {
         POOLBIG("aff_stage2", stage2, t64_bytes(tiles(max_n1), T64_PT_CHUNKS))
 #undef POOLBIG
         const uint32_t max_waves = (uint32_t)g.num_cus * 4u * (uint32_t)FS::WAVES;
-        const bool aff_asm = C::F::DEG >= 2 && gh_asm::aff_enabled() && !h->aff_asm_off;
+        const bool aff_asm = (C::F::DEG >= 2 ? gh_asm::aff_enabled() : gh_asm::aff_g1_enabled()) && !h->aff_asm_off;
+        const int asm_kind = std::is_same<C, Mnt4G2>::value ? 0 : (std::is_same<C, Mnt6G2>::value ? 1 : (std::is_same<C, Mnt6G1>::value ? 3 : 2));
         // the assembly kernels run two waves per SIMD; GH_AFF_WAVES_MUL x that many waves are launched so that the blocks (equal
         // work each) are dealt out dynamically instead of as one exact fill of the chip
         static const int env_wmul = getenv("GH_AFF_WAVES_MUL") ? atoi(getenv("GH_AFF_WAVES_MUL")) : 1;
@@ -976,7 +977,7 @@ struct MsmJob {
                     a.rows = rows; a.in = in; a.sorted = r == 0 ? sorted : nullptr; a.desc = desc + doff; a.n_out = n_out; a.in_base = T(j, r);
                     a.prefix = prefix; a.out = out; a.stage1 = stage1; a.stage2 = stage2; a.groups = waves * TPW; a.bmin = (uint32_t)env_bmin;
                     a.run_if = nullptr;
-                    if constexpr (C::F::DEG >= 2) {
+                    {
                         if (aff_asm) {
                             // The assembly kernels (asmgen/g2_rounds.py): forward pass, tower inversion of the lane groups' running
                             // products, backward pass -- 256 registers, two waves per SIMD, no scratch, no out-of-line product.
@@ -991,9 +992,9 @@ struct MsmJob {
                             q.stage1 = stage1; q.stage2 = stage2; q.out = out; q.accs = asm_accs; q.flag = asm_flag;
                             q.n_out = n_out; q.in_base = T(j, r); q.B = Bq; q.pad = 0;
                             HIPCHK(hipMemsetAsync(asm_flag, 0, 16, st));
-                            if ((rc = gh_asm::aff_launch(C::F::DEG, true, r == 0, q, aw, st))) return rc;
+                            if ((rc = gh_asm::aff_launch(asm_kind, true, r == 0, q, aw, st))) return rc;
                             GH_LAUNCH((aff_inv_kernel<FS>), dim3(aw / 4), dim3(256), 0, st, asm_accs, aw, n_out, Bq, (const uint32_t*)asm_flag);
-                            if ((rc = gh_asm::aff_launch(C::F::DEG, false, r == 0, q, aw, st))) return rc;
+                            if ((rc = gh_asm::aff_launch(asm_kind, false, r == 0, q, aw, st))) return rc;
                             // the listed exceptions (doubling, cancellation, markers), one lane group each; then, only if the list
                             // overflowed, the whole round once more on the C++ kernel
                             if (r == 0) GH_LAUNCH((aff_fix_kernel<C, FS, true>), dim3(16), dim3(256), 0, st, a, (const uint32_t*)asm_flag);

@@ -29,7 +29,7 @@ def _prog(cname, fwd, r0):
     key = (cname, fwd, r0)
     if key not in _PROGS:
         C = pyref.CURVES[cname]
-        cfg = G2.Cfg(C.deg, C.E.nr, C.F.p, R % C.F.p)
+        cfg = G2.Cfg(C.deg, int(C.E.nr or 1), C.F.p, R % C.F.p)
         _PROGS[key] = (G2.build("k_%s_%d%d" % (cname, fwd, r0), cfg, fwd, r0), cfg)
     return _PROGS[key]
 
@@ -139,7 +139,7 @@ def _tower_pt(lst, t, g, L, p):
     return (tuple(xs), tuple(ys))
 
 
-@pytest.mark.parametrize("cname", ["mnt4753_g2", "mnt6753_g2"])
+@pytest.mark.parametrize("cname", ["mnt4753_g2", "mnt6753_g2", "mnt6753_g1"])
 def test_g2_round_kernels_in_the_simulator(cname):
     C = pyref.CURVES[cname]
     p, L = C.F.p, C.deg
@@ -207,7 +207,7 @@ def test_g2_round_kernels_in_the_simulator(cname):
         assert _tower_pt(out1, wv * B2 + k, g, L, p) == exp2[o], o
 
 
-@pytest.mark.parametrize("cname", ["mnt4753_g2", "mnt6753_g2"])
+@pytest.mark.parametrize("cname", ["mnt4753_g2", "mnt6753_g2", "mnt4753_g1"])
 def test_g2_round_kernels_list_the_rare_cases(cname):
     """P + P (the reference's doubling branch, swp.rs:492), P - P and an infinity marker among a pair's inputs do not enter the
     shared inversion: the forward kernel appends such elements to the exception list (aff_fix_kernel recomputes them on the
