@@ -202,7 +202,7 @@ class FieldGen:
         """dst = (a b + c d + e f) 2^-754 mod p for pairs = [(a, b), (c, d), (e, f)] with ONE reduction (fp29.h fp_mul3, which
         restates the Karatsuba-free schoolbook form of fields/models/fp3.rs:453-477 coefficient by coefficient).  A column holds up to
         104 products of 58 bits: it does not fit 64 bits, so two chains each take half (X = a b + c d + carry-in, Y = e f + m p,
-        at most 52 products + 2^36 each) and are joined with a carry bit when the column closes.  Operands need normalised limbs
+        at most 52 products + 2^36 each); when the column closes X's low limb moves over to Y, which closes it as a single chain does.  Operands need normalised limbs
         only (< 2^29); the value is below (3 p^2 + R p) / R < 2.33 p, which can exceed 2^754 by one bit: `top`, folded into
         the first of two conditional subtractions.  dd: scratch slot for them (may be an operand: the columns are done)."""
         g = self.g
@@ -237,21 +237,22 @@ class FieldGen:
                 g.v_and_b32(m.sub(NL - 1), S(self.s_lm), X.lo()); yield
                 g.v_lshrrev_b32(chy.t1, LB, X.lo()); yield          # top
                 break
-            if k < NL:
-                if fy:                                              # k == 0 has e f, so Y is never empty here
-                    raise AssertionError
-                g.v_add_u32(chx.t0, X.lo(), Y.lo()); yield
-                g.v_mul_lo_u32(chx.t0, chx.t0, S(self.s_inv)); yield
-                g.v_and_b32(m.sub(k), S(self.s_lm), chx.t0); yield
-                g.v_mad_u64_u32(Y, chy.sdum, m.sub(k), self.sP(0), Y); yield
-            g.v_add_co_u32(X.lo(), chx.scar, X.lo(), Y.lo()); yield
-            g.v_addc_co_u32(X.hi(), chx.scar, X.hi(), Y.hi(), chx.scar); yield
-            g.v_cndmask_b32(chx.t1, 0, 8, chx.scar); yield         # bit 64 of the column lands on bit 35 of the carry
-            if k >= NL:
-                g.v_and_b32(m.sub(k - NL), S(self.s_lm), X.lo()); yield
+            # Close the column without a 65-bit sum (and without carries through SGPRs, which cost wait states on gfx950):
+            # X's low 29 bits move over to Y (52 products + 2^29 still fit 64 bits), X >> 29 waits; Y closes the column as a
+            # single chain does; the next column starts from (X >> 29) + (Y >> 29).
+            g.v_and_b32(chx.t0, S(self.s_lm), X.lo()); yield
             g.v_alignbit_b32(X.lo(), X.hi(), X.lo(), LB); yield
             g.v_lshrrev_b32(X.hi(), LB, X.hi()); yield
-            g.v_or_b32(X.hi(), X.hi(), chx.t1); yield
+            g.v_mad_u64_u32(Y, chy.sdum, chx.t0, 1, Y); yield
+            if k < NL:
+                g.v_mul_lo_u32(chx.t0, Y.lo(), S(self.s_inv)); yield
+                g.v_and_b32(m.sub(k), S(self.s_lm), chx.t0); yield
+                g.v_mad_u64_u32(Y, chy.sdum, m.sub(k), self.sP(0), Y); yield
+            else:
+                g.v_and_b32(m.sub(k - NL), S(self.s_lm), Y.lo()); yield
+            g.v_alignbit_b32(Y.lo(), Y.hi(), Y.lo(), LB); yield
+            g.v_lshrrev_b32(Y.hi(), LB, Y.hi()); yield
+            g.v_lshl_add_u64(X, Y, 0, X); yield
         # value = m + top 2^754 < 2.33 p: subtract p where top is set or m >= p, then the usual conditional subtraction
         bw, x = chx.t1, chx.t0
         for i in range(NL):

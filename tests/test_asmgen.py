@@ -244,3 +244,48 @@ def test_simulator_refuses_a_register_with_a_result_in_flight():
         else:
             with pytest.raises(RuntimeError, match="in flight"):
                 w.run()
+
+
+@pytest.mark.parametrize("tag", ["p4", "p6"])
+def test_tower_field_routines_in_the_simulator(tag):
+    """field.py routines of the G2 round kernels against Python integers: `triple` (three products with ONE reduction, fp29.h
+    fp_mul3 = the per-lane form of fields/models/fp3.rs:453-477) with the largest reduced operands, `mul_small` (k x - q p, the
+    non-residue factor: value = k x mod p or that plus p, k = 1 the identity) and the lane exchange `bperm`."""
+    p = pyref.FIELDS[tag].p
+    rnd = random.Random(7)
+    g = Prog("t")
+    f = FieldGen(g, p, 24, 50, 21, 20)
+    chA = Chain(V(248, 2), V(252), V(253), S(14, 2), S(16, 2))
+    chB = Chain(V(250, 2), V(254), V(255), S(18, 2), S(22, 2))
+    sl = lambda i: V(20 + NL * i, NL)
+    f.load_constants()
+    lo, hi = f.invc_bits()
+    g.s_mov_b32(S(76), lo)
+    g.s_mov_b32(S(77), hi)
+    run(f.triple(chA, chB, [(sl(0), sl(1)), (sl(2), sl(3)), (sl(4), sl(5))], sl(6), sl(7)))
+    run(f.mul_small(chA, sl(0), V(19), sl(7), S(76, 2)))
+    run(f.bperm(sl(5), V(18), sl(1)))
+    g.s_waitcnt(lgkmcnt=0)
+    g.s_endpgm()
+    vals = [[rnd.randrange(p) for _ in range(64)] for _ in range(6)]
+    for s_ in range(6):
+        vals[s_][0] = p - 1                                     # the column bound and the 2.33 p value bound
+    vals[0][1] = 0
+    ks = [13 if (l & 1) == 0 else 1 for l in range(64)]
+    ks[3] = 15
+    vals[0][3] = p - 1
+    w = Wave(g, Memory())
+    for s_ in range(6):
+        for l in range(64):
+            for i, x in enumerate(limbs(vals[s_][l])):
+                w.V[sl(s_).idx + i][l] = x
+    for l in range(64):
+        w.V[19][l] = ks[l]
+        w.V[18][l] = 4 * (l ^ 1)
+    w.run()
+    get = lambda s_: [unlimbs(w.V[s_.idx:s_.idx + NL, l]) for l in range(64)]
+    ri = pow(R, -1, p)
+    assert get(sl(6)) == [(vals[0][l] * vals[1][l] + vals[2][l] * vals[3][l] + vals[4][l] * vals[5][l]) * ri % p for l in range(64)]
+    for l, v in enumerate(get(sl(7))):
+        assert v % p == ks[l] * vals[0][l] % p and v < p + 27 * (1 << 725) and (ks[l] != 1 or v == vals[0][l]), l
+    assert get(sl(5)) == [vals[1][l ^ 1] for l in range(64)]
