@@ -27,11 +27,12 @@ def kernels_sha():
     """sha256 over the device sources: stamps profiles/*_pmc_traffic.json so that stale counters are not reported"""
     import hashlib
     h = hashlib.sha256()
-    d = os.path.join(ROOT, "ginger-lib_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        if f.endswith((".h", ".hip")):
-            h.update(f.encode())
-            h.update(open(os.path.join(d, f), "rb").read())
+    for sub, ext in (("csrc", (".h", ".hip")), ("asmgen", (".py",))):       # hipcc sources and the generators of the assembly kernels
+        d = os.path.join(ROOT, "ginger-lib_amd", sub)
+        for f in sorted(os.listdir(d)):
+            if f.endswith(ext):
+                h.update(f.encode())
+                h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()
 
 
@@ -374,7 +375,7 @@ def main():
                             "Python integers (tests/support.py chain_msm_closed_form): an answer no MSM code path produced",
         "roofline": {"kernel": "%s (bucket accumulation of the %s MSM)" % (("gh_asm_acc_g1 (generated assembly of msm_accumulate_xyzz_kernel)" if os.environ.get("GH_ACC_ASM", "1") != "0" else "msm_accumulate_xyzz_kernel") if xyzz else "msm_accumulate_kernel / aff_round_kernel", curve), "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_acc,
-                     "traffic_note": "FETCH_SIZE + WRITE_SIZE bytes of the accumulation launches of one MSM from %s (separate rocprofv3 --pmc passes), null when that file was measured on other kernel sources (sha256 of ginger-lib_amd/csrc) or another workload; measured by the builder: %s" % (traffic_src, traffic_when or "box and date unknown"),
+                     "traffic_note": "FETCH_SIZE + WRITE_SIZE bytes of the accumulation launches of one MSM from %s (separate rocprofv3 --pmc passes), null when that file was measured on other kernel sources (sha256 of ginger-lib_amd/csrc and asmgen) or another workload; measured by the builder: %s" % (traffic_src, traffic_when or "box and date unknown"),
                      "avg_launch_ms": acc_avg_ms, "algorithmic_bytes_per_launch": alg_bytes,
                      "note": "integer-VALU bound by construction (SURVEY 8d): see valu"},
         "valu": {"achieved_fpmul_per_s": fpmul_rate, "peak_fpmul_per_s": FPMUL_PEAK_PER_S, "frac": fpmul_rate / FPMUL_PEAK_PER_S,
