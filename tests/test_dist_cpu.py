@@ -71,10 +71,11 @@ def _worker(rank, world, port, curve, n, ret):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("curve,n", [("mnt4753_g1", 37), ("mnt6753_g2", 9)])
-def test_two_rank_sharded_msm(curve, n):
-    world = 2
-    port = 29500 + (os.getpid() % 2000)
+@pytest.mark.parametrize("curve,n,world", [("mnt4753_g1", 37, 2), ("mnt6753_g2", 9, 2), ("mnt6753_g1", 41, 8)])
+def test_two_rank_sharded_msm(curve, n, world):
+    """world 2 on two curves; world 8 = the rank count of BASELINE config 4 (shards of 5 / 6 pairs, the all-gather and the fold in
+    rank order over eight partial sums) rehearsed on CPU ranks over gloo, as the GPU node itself is not the builder's to use"""
+    port = 29500 + (os.getpid() % 2000) + world
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, port, curve, n, ret), nprocs=world, join=True)
