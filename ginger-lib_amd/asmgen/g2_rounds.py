@@ -82,6 +82,10 @@ class Cfg:
         self.row_bytes = 2 * lanes * 104
 
 
+import os as _os
+ABLATE = set(x for x in _os.environ.get("GH_ASM_ABLATE", "").split(",") if x)      # timing experiments only: results are wrong
+
+
 def build(name, cfg, fwd, r0, debug=False):
     """fwd: forward (True) or backward (False) kernel; r0: round 0 (inputs are table rows named by the sorted list, staged by
     the forward kernel) or a later round (inputs in the previous round's T64 list)."""
@@ -135,11 +139,15 @@ def build(name, cfg, fwd, r0, debug=False):
         return V_LDS2, ((which - 2) * NL + w) * PARK_STRIDE
 
     def park_put(which, sl):
+        if "parks" in ABLATE and not fwd:
+            return
         for w in range(NL):
             a, off = park_addr(which, w)
             g.ds_write_b32(a, sl.sub(w), offset=off)
 
     def park_get(which, sl):
+        if "parks" in ABLATE and not fwd:
+            return
         for w in range(NL):
             a, off = park_addr(which, w)
             g.ds_read_b32(sl.sub(w), a, offset=off)
@@ -155,6 +163,8 @@ def build(name, cfg, fwd, r0, debug=False):
     def ld_x_list(sl, saddr, offs):
         """x of a T64 point: chunks 0..5 and the low half of chunk 6.  saddr: S pair + per-lane 32-bit offsets, or None: offs are
         64-bit address pairs"""
+        if "loads" in ABLATE and not fwd:
+            return
         for c in range(6):
             r, imm = list_chunk(c)
             g.global_load_dwordx4(V(sl.idx + 4 * c, 4), offs[r], saddr if saddr is not None else OFF, offset=imm)
@@ -162,6 +172,8 @@ def build(name, cfg, fwd, r0, debug=False):
         g.global_load_dwordx2(V(sl.idx + 24, 2), offs[r], saddr if saddr is not None else OFF, offset=imm)
 
     def ld_y_list(sl, saddr, offs):
+        if "loads" in ABLATE and not fwd:
+            return
         r, imm = list_chunk(6)
         g.global_load_dwordx2(V(sl.idx, 2), offs[r], saddr if saddr is not None else OFF, offset=imm + 8)
         for c in range(6):
@@ -169,6 +181,8 @@ def build(name, cfg, fwd, r0, debug=False):
             g.global_load_dwordx4(V(sl.idx + 2 + 4 * c, 4), offs[r], saddr if saddr is not None else OFF, offset=imm)
 
     def st_x_list(sl, saddr, offs):
+        if "stores" in ABLATE and not fwd:
+            return
         for c in range(6):
             r, imm = list_chunk(c)
             g.global_store_dwordx4(offs[r], V(sl.idx + 4 * c, 4), saddr, offset=imm)
@@ -176,6 +190,8 @@ def build(name, cfg, fwd, r0, debug=False):
         g.global_store_dwordx2(offs[r], V(sl.idx + 24, 2), saddr, offset=imm)
 
     def st_y_list(sl, saddr, offs):
+        if "stores" in ABLATE and not fwd:
+            return
         r, imm = list_chunk(6)
         g.global_store_dwordx2(offs[r], V(sl.idx, 2), saddr, offset=imm + 8)
         for c in range(6):
@@ -183,11 +199,15 @@ def build(name, cfg, fwd, r0, debug=False):
             g.global_store_dwordx4(offs[r], V(sl.idx + 2 + 4 * c, 4), saddr, offset=imm)
 
     def ld_fp_list(sl, saddr, offs):
+        if "loads" in ABLATE and not fwd:
+            return
         for c in range(6):
             g.global_load_dwordx4(V(sl.idx + 4 * c, 4), offs[c // 4], saddr, offset=(c % 4) * 1024)
         g.global_load_dwordx2(V(sl.idx + 24, 2), offs[1], saddr, offset=2 * 1024)
 
     def st_fp_list(sl, saddr, offs):
+        if "stores" in ABLATE and not fwd:
+            return
         for c in range(6):
             g.global_store_dwordx4(offs[c // 4], V(sl.idx + 4 * c, 4), saddr, offset=(c % 4) * 1024)
         g.global_store_dwordx2(offs[1], V(sl.idx + 24, 2), saddr, offset=2 * 1024)
@@ -201,6 +221,12 @@ def build(name, cfg, fwd, r0, debug=False):
     def prep_a(a, a1, a2):
         """the rotated / non-residue-scaled copies of the left operand: a1 = K1 a_(j-1), a2 = K2 a_(j-2)"""
         if L == 1:
+            return
+        if "bperm" in ABLATE and not fwd:
+            if L == 3:
+                interleave(f.mul_small(chA, a1, V_K1, a1, S_INVC), f.mul_small(chB, a2, V_K2, a2, S_INVC))
+            else:
+                run(f.mul_small(chA, a1, V_K1, a1, S_INVC))
             return
         run(f.bperm(a1, V_AP, a))
         if L == 3:
@@ -216,6 +242,8 @@ def build(name, cfg, fwd, r0, debug=False):
         result may take b's slot while bs[0] is still read)"""
         if L == 1:
             run(f.copy(bs[0], b))
+            return
+        if "bperm" in ABLATE and not fwd:
             return
         for i in range(L):
             run(f.bperm(bs[i], V_BC[i], b))
@@ -486,6 +514,8 @@ def build(name, cfg, fwd, r0, debug=False):
         """parts: (slot, address pair, byte offset in the row) -- every lane group reads its own rows: a quarter of the wave at a time,
         all loads of its rows back to back, so that the address translations of its pages stay resident (aff_kernels.h gather_row:
         13 TLB misses per row without it).  The caller waits."""
+        if "loads" in ABLATE and not fwd:
+            return
         g.s_mov_b64(S_T0, EXEC)
         for q in range(4):
             g.s_bfm_b64(S_T1, 16, 16 * q)
