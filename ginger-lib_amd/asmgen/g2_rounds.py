@@ -83,6 +83,10 @@ class Cfg:
 
 
 import os as _os
+# parts of the wave that gather their rows one after the other.  The C++ round kernel and the G1 update gather a quarter of the
+# wave at a time (address translations: aff_kernels.h gather_row); here ONE pass is faster -- a quarter of the load instructions
+# (MNT4-753 G2 2^20: 66.7 -> 64.7 ms per MSM, MNT6-753 G2 2^19: 74.8 -> 73.0; tools/ab_split.sh)
+GATHER_SPLIT = int(_os.environ.get("GH_ASM_GATHER_SPLIT", "1"))
 ABLATE = set(x for x in _os.environ.get("GH_ASM_ABLATE", "").split(",") if x)      # timing experiments only: results are wrong
 
 
@@ -517,9 +521,10 @@ def build(name, cfg, fwd, r0, debug=False):
         if "loads" in ABLATE and not fwd:
             return
         g.s_mov_b64(S_T0, EXEC)
-        for q in range(4):
-            g.s_bfm_b64(S_T1, 16, 16 * q)
-            g.s_and_b64(EXEC, S_T0, S_T1)
+        for q in range(GATHER_SPLIT):
+            if GATHER_SPLIT > 1:
+                g.s_bfm_b64(S_T1, 64 // GATHER_SPLIT, (64 // GATHER_SPLIT) * q)
+                g.s_and_b64(EXEC, S_T0, S_T1)
             for sl, addr, off in parts:
                 for j in range(NL // 2):
                     g.global_load_dwordx2(V(sl.idx + 2 * j, 2), addr, OFF, offset=off + 8 * j)
