@@ -10,7 +10,7 @@ import os
 import subprocess
 import sys
 
-from . import g1_xyzz, g2_rounds, microbench
+from . import g1_xyzz, g2_rounds, microbench, ntt_pass
 from .isa import module_text
 
 LLVM = os.environ.get("GH_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
@@ -34,6 +34,10 @@ def programs():
         for fwd in (True, False):
             for r0 in (True, False):
                 progs.append(g2_rounds.build("gh_asm_aff_%s_%s_%s" % (tag, "fwd" if fwd else "bwd", "r0" if r0 else "rn"), cfg, fwd, r0))
+    # the NTT passes over the scalar fields (MNT4-753 Fr = P6, MNT6-753 Fr = P4), 6 to 8 stages per pass
+    for tag, prime in (("p4", P4), ("p6", P6)):
+        for k in (6, 7, 8):
+            progs.append(ntt_pass.build("gh_asm_ntt_%s_k%d" % (tag, k), prime, k))
     progs.append(microbench.build("gh_asm_mb_mulpair", P4))
     if os.environ.get("GH_ASM_DEBUG"):          # stage markers for tools/asm_g2_check.py (not shipped)
         progs.append(g2_rounds.build("gh_asm_aff_f2_bwd_r0_dbg", c2, False, True, debug=True))

@@ -321,6 +321,44 @@ class FieldGen:
             g.v_subb_co_u32(dst.sub(i), car, dst.sub(i), ch.t0, car); yield
             g.v_and_b32(dst.sub(i), S(self.s_lm), dst.sub(i)); yield
 
+    def sub_plus_p(self, ch, a, b, dst):
+        """dst = a - b + p as normalised limbs (a, b in [0, p): the value is in (0, 2 p) -- an operand for a product whose other
+        operand is fully reduced).  Borrow in a VGPR, no select: 4 instructions per limb.  dst may alias a or b."""
+        g = self.g
+        t, x, c = ch.t0, ch.acc.lo(), ch.t1
+        for i in range(NL):
+            g.v_sub_u32(t, a.sub(i), b.sub(i)); yield
+            if i == 0:
+                g.v_add_u32(x, self.sP(0), t); yield
+            else:
+                g.v_add3_u32(x, t, self.sP(i), c); yield
+            if i + 1 < NL:
+                g.v_ashrrev_i32(c, LB, x); yield
+            g.v_and_b32(dst.sub(i), S(self.s_lm), x); yield
+
+    def add_mod(self, ch, a, b):
+        """a = a + b mod p, fully reduced (a, b in [0, p)); b is destroyed (it holds the digits of a + b - p).  Two carry chains in
+        VGPRs (the sum, and the sum minus p on signed limbs) and one select: 8 instructions per limb."""
+        g = self.g
+        t, u, c1, bw = ch.t0, ch.acc.lo(), ch.acc.hi(), ch.t1
+        for i in range(NL):
+            g.v_add_u32(t, a.sub(i), b.sub(i)); yield
+            if i == 0:
+                g.v_and_b32(a.sub(0), S(self.s_lm), t); yield
+                g.v_lshrrev_b32(c1, LB, t); yield
+                g.v_add_u32(u, self.sNP(0), t); yield
+            else:
+                g.v_add_u32(u, t, c1); yield
+                g.v_lshrrev_b32(c1, LB, u); yield
+                g.v_and_b32(a.sub(i), S(self.s_lm), u); yield
+                g.v_add3_u32(u, t, self.sNP(i), bw); yield
+            g.v_ashrrev_i32(bw, LB, u); yield
+            g.v_and_b32(b.sub(i), S(self.s_lm), u); yield
+        # bw == 0 -> a + b >= p -> take the second chain's digits
+        g.v_cmp_eq_u32(ch.scar, 0, bw); yield
+        for i in range(NL):
+            g.v_cndmask_b32(a.sub(i), a.sub(i), b.sub(i), ch.scar); yield
+
     def neg_sel(self, ch, y, tmp, sel):
         """y = sel ? p - y : y  in place (sel: S pair lane mask; y in [0, p); y == 0 gives p on negated lanes, a harmless
         unreduced zero: products accept it and a - p == a).  tmp: one more scratch VGPR.  Uses the chain's accumulator pair

@@ -172,8 +172,11 @@ class Wave:
     def _check_inflight(self, i):
         op = i.op
         if op == "s_waitcnt":
-            if i.mods.get("vmcnt") == 0:
-                self._inflight_vm = set()
+            if "vmcnt" in i.mods and getattr(self, "_inflight_vm", None) is not None:
+                # vector memory results return in order: vmcnt(N) leaves the N youngest loads (and stores) outstanding
+                keep = int(i.mods["vmcnt"])
+                self._vm_fifo = self._vm_fifo[len(self._vm_fifo) - keep:] if keep else []
+                self._inflight_vm = set().union(*self._vm_fifo) if self._vm_fifo else set()
             if i.mods.get("lgkmcnt") == 0:
                 self._inflight_lgkm = set()
             return
@@ -181,6 +184,7 @@ class Wave:
         if vm is None:
             vm = self._inflight_vm = set()
             self._inflight_lgkm = set()
+            self._vm_fifo = []
         lg = self._inflight_lgkm
         regs = set()
         for a in i.args:
@@ -204,10 +208,14 @@ class Wave:
             dst, pend = i.args[0], lg
         elif op.startswith("s_load"):
             dst, pend = i.args[0], lg
+        if op.startswith("global_store") or (op.startswith("global_atomic") and not i.mods.get("sc0")):
+            self._vm_fifo.append(set())                                       # counted by vmcnt, nothing to protect
         if dst is not None:
             if dst.kind in ("v", "a"):
                 base = dst.idx + (256 if dst.kind == "a" else 0)
                 pend.update(range(base, base + dst.n))
+                if pend is vm:
+                    self._vm_fifo.append(set(range(base, base + dst.n)))
             else:
                 pend.update(-1 - r for r in range(dst.idx, dst.idx + dst.n))
 
@@ -280,6 +288,16 @@ HANDLERS["v_max_u32"] = _bin(lambda a, b: np.maximum(a, b))
 def _mov(w, i):
     d, a = i.args
     w.wr(d, w.rd(a))
+
+
+@op("v_bfrev_b32")
+def _bfrev(w, i):
+    d, a = i.args
+    x = np.asarray(np.broadcast_to(w.rd(a), (LANES,)), dtype=U32)
+    r = np.zeros(LANES, dtype=U32)
+    for b in range(32):
+        r |= ((x >> U32(b)) & U32(1)) << U32(31 - b)
+    w.wr(d, r)
 
 
 @op("v_not_b32")
@@ -533,6 +551,12 @@ def _s64(o, w):
 def _s_mov64(w, i):
     d, a = i.args
     w.wr_smask(d, _s64(a, w))
+
+
+@op("s_cselect_b64")
+def _s_csel64(w, i):
+    d, a, b = i.args
+    w.wr_smask(d, _s64(a, w) if w.scc else _s64(b, w))
 
 
 def _s64bin(fn):

@@ -19,12 +19,14 @@ using gh_rt::g;
 using gh_rt::g_err;
 
 namespace {
+constexpr int NTT_ASM_KMIN = 6, NTT_ASM_KMAX = 8;
 struct State {
     bool tried = false;
     hipModule_t mod = nullptr;
     hipFunction_t acc_g1[2] = {nullptr, nullptr};   // [0]: p4 (MNT4-753 G1), [1]: p6 (MNT6-753 G1)
     hipFunction_t aff[4][2][2] = {};                // [kind: f2, f3, f1p4, f1p6][fwd][r0]
     hipFunction_t mb_mulpair = nullptr;
+    hipFunction_t ntt[2][3] = {};                   // [p4, p6][k - 6]
 };
 State s;
 
@@ -64,6 +66,17 @@ int load_locked() {
                     return GH_E_HIP;
                 }
             }
+    for (int f = 0; f < 2; f++)
+        for (int k = NTT_ASM_KMIN; k <= NTT_ASM_KMAX; k++) {
+            char nm[64];
+            snprintf(nm, sizeof nm, "gh_asm_ntt_p%d_k%d", f ? 6 : 4, k);
+            e = hipModuleGetFunction(&s.ntt[f][k - NTT_ASM_KMIN], m, nm);
+            if (e != hipSuccess) {
+                g_err = std::string("hipModuleGetFunction(") + nm + ") failed: " + hipGetErrorString(e);
+                hipModuleUnload(m);
+                return GH_E_HIP;
+            }
+        }
     e = hipModuleGetFunction(&s.mb_mulpair, m, "gh_asm_mb_mulpair");
     if (e != hipSuccess) {
         g_err = std::string("hipModuleGetFunction(gh_asm_mb_mulpair) failed: ") + hipGetErrorString(e);
@@ -128,6 +141,28 @@ int aff_launch(int tower, bool fwd, bool r0, const AffArgs& a, uint32_t waves, h
     return GH_OK;
 }
 
+bool ntt_enabled() {
+    static const bool on = !(getenv("GH_NTT_ASM") && atoi(getenv("GH_NTT_ASM")) == 0);
+    return on;
+}
+
+// 32-bit byte offsets into the data (96 B per element) and the factor tables (104 B): N <= 2^25
+bool ntt_supported(int log_n, int k) { return k >= NTT_ASM_KMIN && k <= NTT_ASM_KMAX && log_n >= 8 && log_n <= 25 && k <= log_n; }
+
+int ntt_pass_launch(int prime, int k, const NttAsmArgs& a, hipStream_t st) {
+    if (!ntt_supported((int)a.log_n, k) || a.log_ns + (uint32_t)k > a.log_n || a.n_waves != (1u << (a.log_n - 8)) ||
+        (a.post_stride != 0 && a.post_stride != 104)) {
+        g_err = "internal: NTT pass outside the assembly kernel's range";
+        return GH_E_UNSUPPORTED;
+    }
+    if (int rc = load_locked()) return rc;
+    NttAsmArgs args = a;
+    size_t size = sizeof args;
+    void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+    HIPCHK(hipModuleLaunchKernel(s.ntt[prime == 6 ? 1 : 0][k - NTT_ASM_KMIN], (a.n_waves + 3) / 4, 1, 1, 256, 1, 1, 0, st, nullptr, extra));
+    return GH_OK;
+}
+
 int measure_fpmul_peak(double* products_per_s, hipStream_t st) {
     if (int rc = load_locked()) return rc;
     const uint32_t iters = 200, blocks = (uint32_t)g.num_cus * 2u;      // two blocks of 4 waves per CU = two waves per SIMD
@@ -165,6 +200,8 @@ int kernel_resources(const char* which, uint32_t* scratch, uint32_t* vgprs, uint
     else if (w == "g2_f3_fwd_r0") f = s.aff[1][1][1];
     else if (w == "g2_f3_bwd_r0") f = s.aff[1][0][1];
     else if (w == "g2_f3_bwd_rn") f = s.aff[1][0][0];
+    else if (w == "ntt_p4_k8") f = s.ntt[0][2];
+    else if (w == "ntt_p6_k8") f = s.ntt[1][2];
     else { g_err = "unknown kernel name"; return GH_E_BAD_ARG; }
     int v = 0;
     HIPCHK(hipFuncGetAttribute(&v, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, f));

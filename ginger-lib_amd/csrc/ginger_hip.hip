@@ -243,6 +243,8 @@ int gh_shutdown(void) try {
             if (d.coset) hipFree(d.coset);
             if (d.coset_inv) hipFree(d.coset_inv);
             if (d.scratch) hipFree(d.scratch);
+            if (d.scratch2) hipFree(d.scratch2);
+            if (d.d_size_inv) hipFree(d.d_size_inv);
         }
         g.domains[f].clear();
     }

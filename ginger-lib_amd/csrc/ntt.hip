@@ -2,6 +2,7 @@
 #include "runtime.h"
 #include "ntt_kernels.h"
 #include "host_math.h"
+#include "asm_kernels.h"
 
 namespace gh_rt {
 using namespace gh;
@@ -61,6 +62,12 @@ template <class P> int get_domain(int fidx, int log_n, bool need_coset, bool nee
         if (e != hipSuccess) { g_err = std::string("domain scratch: ") + hipGetErrorString(e); return e == hipErrorOutOfMemory ? GH_E_NOMEM : GH_E_HIP; }
         int rc = build_table_checked<P>(&d.tw, log_n, fp_one<P>(), w);
         if (rc) { hipFree(d.scratch); return rc; }
+        if (hipMalloc((void**)&d.d_size_inv, 128) != hipSuccess ||
+            hipMemcpy(d.d_size_inv, &d.size_inv, sizeof(Fp), hipMemcpyHostToDevice) != hipSuccess) {
+            g_err = "domain constants: device allocation failed";
+            hipFree(d.scratch); hipFree(d.tw); if (d.d_size_inv) hipFree(d.d_size_inv);
+            return GH_E_NOMEM;
+        }
         it = g.domains[fidx].emplace(log_n, d).first;
     }
     Domain& d = it->second;
@@ -104,13 +111,29 @@ template <class P> int fft_run(int fidx, void* d_data, uint32_t log_n, uint32_t 
                                    hipFuncAttributeMaxDynamicSharedMemorySize, NL * 4 * NTT_MAX_TILE));
         attr_set[fidx] = true;
     }
+    // Ping-pong: with an even number of passes the caller's vector and the domain's scratch alternate; with an odd number (2^24:
+    // three) a second scratch vector lets the last pass write into the caller's vector instead of a 3.2 GB copy at the end.
+    if (P_ >= 3 && (P_ & 1) && !d->scratch2 && !d->scratch2_failed) {
+        if (hipMalloc((void**)&d->scratch2, ((size_t)96) << log_n) != hipSuccess) {
+            (void)hipGetLastError();
+            d->scratch2 = nullptr;
+            d->scratch2_failed = true;
+        }
+    }
+    const bool three = P_ >= 3 && (P_ & 1) && d->scratch2;
     uint32_t* bufs[2] = {(uint32_t*)d_data, d->scratch};
     int cur = 0, log_ns = 0;
+    static const bool ntt_asm = gh_asm::ntt_enabled();
     HIPCHK(hipEventRecord(g.ev[4], g.stream));
     for (int s = 0; s < P_; s++) {
         NttPassArgs A;
         A.in = bufs[cur];
         A.out = bufs[cur ^ 1];
+        if (three) {          // data -> scratch -> scratch2 -> data, then the usual alternation data <-> scratch
+            if (s == 0) { A.in = (uint32_t*)d_data; A.out = d->scratch; }
+            else if (s == 1) { A.in = d->scratch; A.out = d->scratch2; }
+            else if (s == 2) { A.in = d->scratch2; A.out = (uint32_t*)d_data; }
+        }
         A.tw = d->tw;
         A.pre = (s == 0 && coset && !inverse) ? d->coset : nullptr;
         A.post = nullptr;
@@ -130,8 +153,20 @@ template <class P> int fft_run(int fidx, void* d_data, uint32_t log_n, uint32_t 
         int threads = E / 2;
         if (threads < 64) threads = 64;
         const unsigned grid = 1u << ((int)log_n - ks[s] - log_c);
-        hipLaunchKernelGGL((ntt_pass_kernel<P>), dim3(grid), dim3(threads), (size_t)NL * 4 * E, g.stream, A);
-        cur ^= 1;
+        if (ntt_asm && gh_asm::ntt_supported((int)log_n, ks[s])) {
+            // the assembly pass (asmgen/ntt_pass.py): same indices and factors, a wave per 256 elements
+            gh_asm::NttAsmArgs q;
+            q.in = A.in; q.out = A.out; q.tw = A.tw; q.pre = A.pre;
+            q.post = A.post ? (const void*)A.post : (A.has_post_scalar ? (const void*)d->d_size_inv : nullptr);
+            q.post_stride = A.post ? 104u : 0u;
+            q.log_n = log_n; q.log_ns = (uint32_t)log_ns; q.inverse = (uint32_t)A.inverse;
+            q.n_waves = 1u << (log_n - 8); q.pad = 0;
+            if ((rc = gh_asm::ntt_pass_launch(std::is_same<P, P6>::value ? 6 : 4, ks[s], q, g.stream))) return rc;
+        } else {
+            hipLaunchKernelGGL((ntt_pass_kernel<P>), dim3(grid), dim3(threads), (size_t)NL * 4 * E, g.stream, A);
+        }
+        if (three && s < 3) cur = s == 2 ? 0 : 1;      // after pass 2 the result is in the caller's vector
+        else cur ^= 1;
         log_ns += ks[s];
     }
     HIPCHK(hipGetLastError());

@@ -20,7 +20,10 @@ struct Domain {
     gh::Fp* coset = nullptr;       // g^i
     gh::Fp* coset_inv = nullptr;   // size_inv * g^-i
     gh::Fp size_inv;               // internal form
+    gh::Fp* d_size_inv = nullptr;  // the same on the device (the assembly pass reads its final factor from memory)
     uint32_t* scratch = nullptr;
+    uint32_t* scratch2 = nullptr;  // second ping-pong vector: an odd number of passes ends in the caller's buffer without a copy
+    bool scratch2_failed = false;
 };
 
 struct DevBuf {
