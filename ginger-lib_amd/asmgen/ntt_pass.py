@@ -9,8 +9,15 @@ Why assembly: the C++ pass exchanges the butterflies' operands through LDS (26 w
 a block barrier per stage) and spills 160 bytes per lane.  Here ONE WAVE owns 256 elements = 2^k rows x 2^(8-k) columns,
 four per lane, and a stage is two in-lane butterflies: the two top row bits start in-lane, every further stage first
 swaps one in-lane bit with a lane bit (two ds_bpermute_b32 + two selects per limb: no LDS memory, no barrier, waves are
-independent) -- and the arithmetic is the hand-allocated product of field.py: per butterfly a - b + p (4 instructions
-per limb, no select: the product takes an operand below 2 p), a + b mod p (8 per limb), one Montgomery product.
+independent) -- and the arithmetic is the hand-allocated product of field.py.
+
+Fewer products than the C++ pass (16 per lane and pass instead of 18): the inter-pass twiddle w^(c t), c = kk << sh, is not
+multiplied in.  A column's transform is the evaluation of its polynomial at theta w_R^u, theta = w^c -- a DFT on a coset -- and
+splitting by the top row bit keeps that shape: the even outputs are the half-size transform of a + theta^h b with the same
+shift, the odd ones that of a - theta^h b with shift theta w_R.  So every stage is (a, b) <- (a + v b, a - v b) with
+v = (the sub-transform's shift)^h = w^e, e = (kk << (sh + beta)) + (rev << (ssh + beta)), rev = the bit-reversed row bits above
+beta: one product per butterfly, the inter-pass factor included; in pass 0 (c = 0) the first stage and half of the second
+have v = 1.  Same outputs at the same indices as the C++ pass.
 
 Register plan (232 VGPRs, two waves per SIMD, no scratch, no LDS allocation):
   v0 tid | v1 lane | v2 tl = lane >> log_c | v3 column j | v4 kk | v5..v19 indices and temporaries
@@ -119,15 +126,15 @@ def build(name, p, k):
         g.v_mul_lo_u32(dst, dst, S_104)
 
     def butterfly(x, y, tw):
-        """(x, y) <- (x + y, (x - y) tw); tw None: the stage's twiddle is one"""
+        """(x, y) <- (x + tw y, x - tw y); tw None: the factor is one"""
         if tw is None:
             run(f.sub(ch, x, y, D))
             run(f.add_mod(ch, x, y))
             run(f.copy(y, D))
         else:
-            run(f.sub_plus_p(ch, x, y, D))
-            run(f.add_mod(ch, x, y))
-            run(f.mul(ch, D, tw, M, D, dst=y))
+            run(f.mul(ch, y, tw, M, D, dst=D))
+            run(f.sub(ch, x, D, y))
+            run(f.add_mod(ch, x, D))
 
     def times(x, tw):
         """x <- x tw (tw is dead afterwards: it serves the conditional subtraction)"""
@@ -180,8 +187,8 @@ def build(name, p, k):
         g.s_waitcnt(vmcnt=6 * (3 - a))
         unpack(E[a], STAGE[a])
 
-    # ------------------------------------------------------------ optional coset factor, inter-pass twiddle
-    L_NOPRE, L_NOTW = g.uniq("nopre"), g.uniq("notw")
+    # ------------------------------------------------------------ optional coset factor
+    L_NOPRE = g.uniq("nopre")
     S_JMP = S(92, 2)
     g.s_cmp_eq_u64(S_PRE, 0)
     g.s_cbranch_scc0(g_pre := g.uniq("pre"))
@@ -200,29 +207,14 @@ def build(name, p, k):
         times(E[a], cur)
     g.label(L_NOPRE)
 
-    g.s_cmp_eq_u32(S_LOGNS, 0)
-    g.s_cbranch_scc0(g_tw := g.uniq("tw"))
-    g.long_branch(L_NOTW, S_JMP)
-    g.label(g_tw)
-    for a in range(4):
-        g.v_mul_lo_u32(V_T[a], V_T[a], V_KK)                        # kk t_a < 2^(log_ns + k)
-        g.v_lshlrev_b32(V_T[a], S_SH, V_T[a])
-        tw_offset(V_OFF[a], V_T[a])
-    load_fp(TWA, V_OFF[0], S_TW)
-    for a in range(4):
-        cur, nxt = (TWA, TWB) if a % 2 == 0 else (TWB, TWA)
-        if a + 1 < 4:
-            load_fp(nxt, V_OFF[a + 1], S_TW)
-            g.s_waitcnt(vmcnt=NL // 2)
-        else:
-            g.s_waitcnt(vmcnt=0)
-        times(E[a], cur)
-    g.label(L_NOTW)
 
     # ------------------------------------------------------------ the k stages
     # inl[b] = the row bit that in-lane bit b holds; lane bit q >= log_c holds row bit q - log_c until it is swapped in
     inl = [k - 2, k - 1]
-    V_BP, V_E = V_T[4], V_T[5]
+    V_BP, V_E, V_REV = V_T[4], V_T[5], V_T[3]
+    S_T2 = S(94)
+    g.v_bfrev_b32(V_REV, V_TL)
+    g.v_lshrrev_b32(V_REV, 32 - (k - 2), V_REV)                     # the row bits the lanes hold (tl has k - 2 bits), reversed
     for beta in range(k - 1, -1, -1):
         last = beta == 0
         if beta in inl:
@@ -232,24 +224,28 @@ def build(name, p, k):
             b = 0 if inl[0] > inl[1] else 1                         # the in-lane bit done longest ago goes out to the lanes
             swap_q = beta + log_c
         pairs = [(0, 2), (1, 3)] if b == 1 else [(0, 1), (2, 3)]
-        # the stage's twiddle(s): w^(i N / 2^(beta+1)), i = the row's bits below beta
-        other = inl[1 - b] if swap_q is None else None
-        tws = []
-        if not last:
-            lowbits = min(beta, k - 2)
-            g.s_sub_u32(S_T1, S_LOGN, beta + 1)
-            variants = [0, 1] if (other is not None and other < beta) else [0]
-            for vi in variants:
-                if lowbits < k - 2:
-                    g.v_and_b32(V_E, (1 << lowbits) - 1, V_TL)
-                else:
-                    g.v_mov_b32(V_E, V_TL)
-                if vi:
-                    g.v_or_b32(V_E, 1 << other, V_E)
-                g.v_lshlrev_b32(V_E, S_T1, V_E)
-                tw_offset(V_T[vi], V_E)
-                load_fp((TWA, TWB)[vi], V_T[vi], S_TW)
-                tws.append((TWA, TWB)[vi])
+        # the stage's factors w^e, e = (kk << (sh + beta)) + (rev << (ssh + beta)); rev = reversed row bits above beta: those in the
+        # lanes (V_REV, its low k - 2 - beta bits) and the other in-lane bit (bit k - 2 - beta: clear for the first pair, set for the second)
+        g.s_add_u32(S_T1, S_SH, beta)
+        g.s_add_u32(S_T2, S_SSH, beta)
+        g.v_lshlrev_b32(V_E, S_T1, V_KK)
+        tws = [TWA]
+        if beta <= k - 2:
+            nrev = k - 2 - beta
+            if nrev > 0:
+                g.v_and_b32(V_T[0], (1 << nrev) - 1, V_REV)
+                g.v_lshlrev_b32(V_T[0], S_T2, V_T[0])
+                g.v_add_u32(V_T[0], V_T[0], V_E)
+            else:
+                g.v_mov_b32(V_T[0], V_E)
+            g.s_lshl_b32(S_T1, 1 << nrev, S_T2)
+            g.v_add_u32(V_T[1], S_T1, V_T[0])
+            g.v_mov_b32(V_E, V_T[0])
+            tw_offset(V_T[1], V_T[1])
+            load_fp(TWB, V_T[1], S_TW)
+            tws.append(TWB)
+        tw_offset(V_T[0], V_E)
+        load_fp(TWA, V_T[0], S_TW)
         if swap_q is not None:
             # in-lane bit b <-> lane bit swap_q: lanes with the bit clear give their upper element and take the partner's lower one
             g.v_xor_b32(V_BP, 1 << swap_q, V_LANE)
@@ -264,56 +260,59 @@ def build(name, p, k):
                     g.v_cndmask_b32(E[y].sub(w), M.sub(w), E[y].sub(w), S_MASK)
                     g.v_cndmask_b32(E[x].sub(w), E[x].sub(w), D.sub(w), S_MASK)
             inl[b] = beta
-        if not last:
-            g.s_waitcnt(vmcnt=0)
-            for n, (x, y) in enumerate(pairs):
-                # with two twiddles (the first stage) the pair whose lower element has the other in-lane bit set takes the second
-                tw = tws[0]
-                if len(tws) == 2 and ((x >> (1 - b)) & 1):
-                    tw = tws[1]
-                butterfly(E[x], E[y], tw)
-        else:
-            # ---------------------------------------------------- last stage: output indices, optional final factor, store
-            # row t = (tl << 2) | in-lane bits; output index oa = jbase + (bitrev_k(t) << log_ns), jbase = ((j - kk) << k) + kk
-            g.v_sub_u32(V_T[0], V_J, V_KK)
-            g.v_lshlrev_b32(V_T[0], k, V_T[0])
-            g.v_add_u32(V_T[0], V_T[0], V_KK)                       # jbase
-            g.v_lshlrev_b32(V_T[1], 2, V_TL)
-            g.v_bfrev_b32(V_T[1], V_T[1])
-            g.v_lshrrev_b32(V_T[1], 32 - k, V_T[1])                 # bitrev_k(tl << 2)
-            for a in range(4):
-                t_low = (((a >> 0) & 1) << inl[0]) | (((a >> 1) & 1) << inl[1])
-                rev = int(format(t_low, "0%db" % k)[::-1], 2)
-                g.v_or_b32(V_IDX[a], rev, V_T[1])
-                g.v_lshlrev_b32(V_IDX[a], S_LOGNS, V_IDX[a])
-                g.v_add_u32(V_IDX[a], V_IDX[a], V_T[0])
-            L_NOPOST, L_STORE = g.uniq("nopost"), g.uniq("store")
-            g.s_cmp_eq_u64(S_POST, 0)
-            g.s_cbranch_scc0(g_post := g.uniq("post"))
-            g.long_branch(L_NOPOST, S_JMP)
-            g.label(g_post)
-            for a in range(4):
-                g.v_mul_lo_u32(V_OFF[a], V_IDX[a], S_PSTRIDE)
-            for (x, y) in pairs:
-                load_fp(TWA, V_OFF[x], S_POST)
-                load_fp(TWB, V_OFF[y], S_POST)
-                run(f.sub_plus_p(ch, E[x], E[y], D))
-                run(f.add_mod(ch, E[x], E[y]))
-                g.s_waitcnt(vmcnt=0)
-                run(f.mul(ch, D, TWB, M, D, dst=E[y]))
-                times(E[x], TWA)
-            g.long_branch(L_STORE, S_JMP)
-            g.label(L_NOPOST)
-            for (x, y) in pairs:
+        g.s_waitcnt(vmcnt=0)
+        for n, (x, y) in enumerate(pairs):
+            tw = tws[min(n, len(tws) - 1)]
+            if beta == k - 1 or (beta == k - 2 and n == 0):
+                # rev == 0: in pass 0 (log_ns == 0, kk == 0) the factor is one
+                L_FULL, L_NEXT = g.uniq("full"), g.uniq("next")
+                g.s_cmp_eq_u32(S_LOGNS, 0)
+                g.s_cbranch_scc0(L_FULL)
                 butterfly(E[x], E[y], None)
-            g.label(L_STORE)
-            for a in range(4):
-                g.v_mul_lo_u32(V_OFF[a], V_IDX[a], S_96)
-            for a in range(4):
-                pack(STAGE[a], E[a])
-                for q in range(6):
-                    g.global_store_dwordx4(V_OFF[a], V(STAGE[a].idx + 4 * q, 4), S_OUT, offset=16 * q)
-            g.s_endpgm()
+                g.long_branch(L_NEXT, S_JMP)
+                g.label(L_FULL)
+                butterfly(E[x], E[y], tw)
+                g.label(L_NEXT)
+            else:
+                butterfly(E[x], E[y], tw)
+    # ------------------------------------------------------------ output indices, optional final factor, store
+    # row t = (tl << 2) | in-lane bits; output index oa = jbase + (bitrev_k(t) << log_ns), jbase = ((j - kk) << k) + kk
+    g.v_sub_u32(V_T[0], V_J, V_KK)
+    g.v_lshlrev_b32(V_T[0], k, V_T[0])
+    g.v_add_u32(V_T[0], V_T[0], V_KK)                               # jbase
+    g.v_lshlrev_b32(V_T[1], 2, V_TL)
+    g.v_bfrev_b32(V_T[1], V_T[1])
+    g.v_lshrrev_b32(V_T[1], 32 - k, V_T[1])                         # bitrev_k(tl << 2)
+    for a in range(4):
+        t_low = (((a >> 0) & 1) << inl[0]) | (((a >> 1) & 1) << inl[1])
+        rev = int(format(t_low, "0%db" % k)[::-1], 2)
+        g.v_or_b32(V_IDX[a], rev, V_T[1])
+        g.v_lshlrev_b32(V_IDX[a], S_LOGNS, V_IDX[a])
+        g.v_add_u32(V_IDX[a], V_IDX[a], V_T[0])
+    L_STORE = g.uniq("store")
+    g.s_cmp_eq_u64(S_POST, 0)
+    g.s_cbranch_scc0(g_post := g.uniq("post"))
+    g.long_branch(L_STORE, S_JMP)
+    g.label(g_post)
+    for a in range(4):
+        g.v_mul_lo_u32(V_OFF[a], V_IDX[a], S_PSTRIDE)
+    load_fp(TWA, V_OFF[0], S_POST)
+    for a in range(4):
+        cur, nxt = (TWA, TWB) if a % 2 == 0 else (TWB, TWA)
+        if a + 1 < 4:
+            load_fp(nxt, V_OFF[a + 1], S_POST)
+            g.s_waitcnt(vmcnt=NL // 2)
+        else:
+            g.s_waitcnt(vmcnt=0)
+        times(E[a], cur)
+    g.label(L_STORE)
+    for a in range(4):
+        g.v_mul_lo_u32(V_OFF[a], V_IDX[a], S_96)
+    for a in range(4):
+        pack(STAGE[a], E[a])
+        for q in range(6):
+            g.global_store_dwordx4(V_OFF[a], V(STAGE[a].idx + 4 * q, 4), S_OUT, offset=16 * q)
+    g.s_endpgm()
     g.label(L_END)
     g.s_endpgm()
     g.hazard_nops = fix_hazards(g)
