@@ -317,9 +317,9 @@ def main():
     if rank == 0:
         try:
             peak_now = gl.measure_fpmul_peak()
-            hot_kernels = {k: gl.kernel_resources(k) for k in ("g1_acc_p4", "g2_f2_bwd_r0", "g2_f3_bwd_r0")}
+            hot_kernels = {k: gl.kernel_resources(k) for k in ("g1_acc_p4", "g2_f2_bwd_r0", "g2_f3_bwd_r0", "ntt_p6_k8")}
             hot_kernels["note"] = ("generated gfx950 assembly (ginger-lib_amd/asmgen): G1 XYZZ bucket update, backward kernels of the Fq2 / Fq3 affine "
-                                   "rounds; scratch_bytes_per_lane / registers / lds_bytes as hipFuncGetAttribute reports them for the loaded code object")
+                                   "rounds, the 8-stage NTT pass; scratch_bytes_per_lane / registers / lds_bytes as hipFuncGetAttribute reports them for the loaded code object")
         except gl.GingerHipError as e:
             hot_kernels = {"error": str(e)}
 
@@ -591,7 +591,13 @@ def main():
         out["ntt"] = {"field": "MNT4-753 Fr", "log_n": args.ntt_log_n, "ms": ntt_ms, "wall_ms": float(np.mean(walls)),
                       "transforms": "fft, ifft, coset_fft, coset_ifft cycled; device resident, in place",
                       "host_to_host_ms": h2h_ms, "host_to_host_note": "gh_fft from / to pageable host memory (PCIe both ways), one call; never the headline",
-                      "roofline": {"kernel": "ntt_pass_kernel<P6> (all passes of one transform)", "bound": "hbm",
+                      # the passes are bound by the issue rate of the 753-bit products, not by HBM: log_n / 2 products per element on average
+                      # over the four kinds (a butterfly = one product, the inter-pass twiddle folded in: asmgen/ntt_pass.py)
+                      "valu": {"fp_products_per_element": args.ntt_log_n / 2.0,
+                               "achieved_fpmul_per_s": N * (args.ntt_log_n / 2.0) / (ntt_ms * 1e-3),
+                               "peak_fpmul_per_s_measured_now": peak_now,
+                               "frac_of_measured_peak": (N * (args.ntt_log_n / 2.0) / (ntt_ms * 1e-3) / peak_now) if peak_now else None},
+                      "roofline": {"kernel": "gh_asm_ntt_p6_k* (generated assembly; all passes of one transform)", "bound": "hbm",
                                    "achieved": nb / (ntt_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": nb / (ntt_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic_ntt,
                                    "traffic_note": "raw FETCH_SIZE + WRITE_SIZE; MI355X_MICROARCH.md: on gfx950 FETCH_SIZE under-reports wide coalesced "

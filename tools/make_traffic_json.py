@@ -35,7 +35,7 @@ def last_msm_bytes(path, counter):
 
 
 def ntt_bytes(path, counter):
-    rows = [r for r in per_dispatch(path, counter) if "ntt_pass_kernel" in r[1]]
+    rows = [r for r in per_dispatch(path, counter) if "ntt_pass_kernel" in r[1] or "gh_asm_ntt" in r[1]]
     # passes of the last transform: the launches after the last gap are identical in count per transform; take the last 3 (2^24) / all / n
     n_pass = 3
     return sum(v for _, _, v in rows[-n_pass:]) * 1024.0
