@@ -295,7 +295,8 @@ int gh_fft_last_kernel_ms(float* ms);
  * full-chip launch runs two interleaved products per iteration on the register plan of the hot kernels (asmgen/microbench.py).
  * bench.py prices `valu.frac` against it.  gh_kernel_resources: scratch bytes per lane (stack frame; spills), registers and
  * LDS bytes of a generated kernel as the loaded code object reports them; `which` is one of g1_acc_p4, g1_acc_p6,
- * g2_f2_fwd_r0, g2_f2_bwd_r0, g2_f2_bwd_rn, g2_f3_fwd_r0, g2_f3_bwd_r0, g2_f3_bwd_rn. */
+ * g2_f2_fwd_r0, g2_f2_bwd_r0, g2_f2_bwd_rn, g2_f3_fwd_r0, g2_f3_bwd_r0, g2_f3_bwd_rn, ntt_p4_k8, ntt_p6_k8 (the 8-stage NTT pass
+ * over MNT6-753 Fr / MNT4-753 Fr). */
 int gh_measure_fpmul_peak(double* products_per_s);
 int gh_kernel_resources(const char* which, uint32_t* scratch_bytes_per_lane, uint32_t* registers, uint32_t* lds_bytes);
 
