@@ -513,3 +513,39 @@ def test_cfg5_key_generated_on_device_at_2p20_and_proof_in_closed_form(gpu):
     C_s = (sum(asg[i] * l[i] for i in range(3, len(asg))) + H + s_ * A_s + r_ * B_s - r_ * s_ * delta) % r
     exp = G.wire(C1, C1.mul(A_s, g1)) + G.wire(C2, C2.mul(B_s, g2)) + G.wire(C1, C1.mul(C_s, g1))
     assert proof == exp
+
+
+# ------------------------------------------------------------------------------ the transforms at 2^24 and at the largest size of the assembly pass
+@pytest.mark.parametrize("log_n", [24, 25])
+def test_ntt_full_size_sparse_input_against_closed_form(gpu, log_n):
+    """2^24 (the bench's size) and 2^25 (the largest domain whose passes run as generated assembly: 32-bit byte offsets): a vector with a
+    handful of non-zero coefficients has every output in closed form, X[k] = sum x_n (g^n) w^(n k) (domain.rs:113-179), whatever the
+    size -- checked at the ends and at random indices for fft and coset_fft; ifft / coset_ifft then return the input bit for bit."""
+    F = S.FIELD_OF["mnt4753_fr"]
+    p = F.p
+    n = 1 << log_n
+    rnd = np.random.default_rng(500 + log_n)
+    pos = sorted({0, 1, n - 1, n // 2 + 1} | {int(v) for v in rnd.integers(0, n, size=4)})
+    vals = [int.from_bytes(rnd.bytes(96), "little") % p for _ in pos]
+    a = np.zeros((n, 12), dtype=np.uint64)
+    a[pos] = S.fe_array(F, vals)
+    w = pyref.domain_params(F, log_n)
+    g = F.generator
+    ks = sorted({0, 1, n - 1, n // 2, n // 2 - 1} | {int(v) for v in rnd.integers(0, n, size=40)})
+    dom = gpu.EvaluationDomain("mnt4753_fr", n)
+    buf = gpu.DeviceBuffer(n * 96).upload(a)
+    try:
+        for fwd, inv, coset in ((0, 1, False), (2, 3, True)):
+            dom.fft_dev(buf, fwd)
+            out = buf.download().reshape(n, 12)
+            got = S.fe_list(F, out[ks])
+            for k, gk in zip(ks, got):
+                exp = sum(v * (pow(g, q, p) if coset else 1) * pow(w, (q * k) % n, p) for q, v in zip(pos, vals)) % p
+                assert gk == exp, (log_n, coset, k)
+            del out
+            dom.fft_dev(buf, inv)
+            back = buf.download().reshape(n, 12)
+            assert (back == a).all(), (log_n, coset)
+            del back
+    finally:
+        buf.free()
