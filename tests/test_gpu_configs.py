@@ -516,9 +516,10 @@ def test_cfg5_key_generated_on_device_at_2p20_and_proof_in_closed_form(gpu):
 
 
 # ------------------------------------------------------------------------------ the transforms at 2^24 and at the largest size of the assembly pass
-@pytest.mark.parametrize("log_n", [24, 25])
+@pytest.mark.parametrize("log_n", [24, 25, 26])
 def test_ntt_full_size_sparse_input_against_closed_form(gpu, log_n):
-    """2^24 (the bench's size) and 2^25 (the largest domain whose passes run as generated assembly: 32-bit byte offsets): a vector with a
+    """2^24 (the bench's size), 2^25 (the largest domain whose passes run as generated assembly: 32-bit byte offsets) and 2^26 (the
+    C++ pass with 64-bit offsets; 6.4 GB of data): a vector with a
     handful of non-zero coefficients has every output in closed form, X[k] = sum x_n (g^n) w^(n k) (domain.rs:113-179), whatever the
     size -- checked at the ends and at random indices for fft and coset_fft; ifft / coset_ifft then return the input bit for bit."""
     F = S.FIELD_OF["mnt4753_fr"]
