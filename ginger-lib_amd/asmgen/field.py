@@ -76,8 +76,7 @@ class FieldGen:
         g.v_mul_lo_u32(ch.t0, ch.acc.lo(), S(self.s_inv)); yield
         g.v_and_b32(m.sub(k), S(self.s_lm), ch.t0); yield
         g.v_mad_u64_u32(ch.acc, ch.sdum, m.sub(k), self.sP(0), ch.acc); yield
-        g.v_alignbit_b32(ch.acc.lo(), ch.acc.hi(), ch.acc.lo(), LB); yield
-        g.v_lshrrev_b32(ch.acc.hi(), LB, ch.acc.hi()); yield
+        g.v_lshrrev_b64(ch.acc, LB, ch.acc); yield                  # one full-rate 64-bit shift (tools/asm_mb: ic_lshr64)
 
     def _close_high(self, ch, r, k, last_unmasked=False):
         g = self.g
@@ -89,8 +88,7 @@ class FieldGen:
             yield
             return
         g.v_and_b32(r.sub(k - NL), S(self.s_lm), ch.acc.lo()); yield
-        g.v_alignbit_b32(ch.acc.lo(), ch.acc.hi(), ch.acc.lo(), LB); yield
-        g.v_lshrrev_b32(ch.acc.hi(), LB, ch.acc.hi()); yield
+        g.v_lshrrev_b64(ch.acc, LB, ch.acc); yield
 
     def mont_columns(self, ch, ab_terms, m, r=None):
         """The 52 columns of a Montgomery product.  ab_terms(k) -> list of (x, y) register pairs whose products form
@@ -168,34 +166,16 @@ class FieldGen:
 
     def dual(self, chx, chy, a, b, c, d, m, dd, dst=None):
         """dst = (a b + c d) 2^-754 mod p with ONE reduction (fp29.h fp_mul2s: all four operands fully reduced, which
-        bounds every column below 2^64).  Two accumulator chains: a b on chx, c d on chy, the m p terms alternate; joined
-        when a column closes.  dd: scratch slot for the conditional subtraction (e.g. c, dead after the columns)."""
-        g = self.g
-        fx = fy = True
-        for k in range(2 * NL):
+        bounds every column below 2^64), on ONE accumulator chain: the a b terms of a column, then its c d terms, then
+        m p.  (Until round 4 the two products ran on two alternating chains, joined when a column closed: 2 % slower on the card,
+        tools/asm_mb dual against dual_one_chain -- a mad that takes its addend from its predecessor is the cheaper one.)  chy is
+        unused; dd: scratch slot for the conditional subtraction (e.g. c, dead after the columns)."""
+        def terms(k):
             lo = max(0, k - NL + 1)
             hi = min(k, NL - 1)
-            seq = []
-            for i in range(lo, hi + 1):
-                seq.append((0, a.sub(i), b.sub(k - i)))
-                seq.append((1, c.sub(i), d.sub(k - i)))
-            mlo = 0 if k < NL else k - NL + 1
-            mhi = k - 1 if k < NL else NL - 1
-            for n, i in enumerate(range(mlo, mhi + 1)):
-                seq.append((n & 1, m.sub(i), self.sP(k - i)))
-            ny = False
-            for which, x, y in seq:
-                if which == 0:
-                    self._mad(chx, x, y, fx); fx = False
-                else:
-                    self._mad(chy, x, y, not ny); ny = True
-                yield
-            if ny:
-                g.v_lshl_add_u64(chx.acc, chy.acc, 0, chx.acc); yield
-            if k < NL:
-                yield from self._close_low(chx, m, k)
-            else:
-                yield from self._close_high(chx, m, k)
+            return ([(a.sub(i), b.sub(k - i)) for i in range(lo, hi + 1)] +
+                    [(c.sub(i), d.sub(k - i)) for i in range(lo, hi + 1)])
+        yield from self.mont_columns(chx, terms, m)
         yield from self.cond_sub(chx, m, dd, m if dst is None else dst)
 
     def triple(self, chx, chy, pairs, m, dd, dst=None):
@@ -222,17 +202,12 @@ class FieldGen:
             for i in range(mlo, mhi + 1):
                 ys.append((m.sub(i), self.sP(k - i)))
             fy = True
-            ix = iy = 0
-            while ix < len(xs) or iy < len(ys):                    # alternate the chains: no mad waits for its predecessor
-                if ix < len(xs):
-                    x, y = xs[ix]; ix += 1
-                    g.v_mad_u64_u32(X, chx.sdum, x, y, 0 if fx else X); fx = False; yield
-                if iy < len(ys):
-                    x, y = ys[iy]; iy += 1
-                    g.v_mad_u64_u32(Y, chy.sdum, x, y, 0 if fy else Y); fy = False; yield
-                if ix < len(xs) and len(xs) - ix > len(ys) - iy:   # X has twice the product terms: catch up
-                    x, y = xs[ix]; ix += 1
-                    g.v_mad_u64_u32(X, chx.sdum, x, y, 0 if fx else X); fx = False; yield
+            # one chain after the other: a mad whose addend is its predecessor's result is the cheap one (alternating the chains
+            # measured 5 % slower: tools/asm_mb g2_triple against g2_triple_seq)
+            for x, y in xs:
+                g.v_mad_u64_u32(X, chx.sdum, x, y, 0 if fx else X); fx = False; yield
+            for x, y in ys:
+                g.v_mad_u64_u32(Y, chy.sdum, x, y, 0 if fy else Y); fy = False; yield
             if k == 2 * NL - 1:                                     # only the carry of column 50
                 g.v_and_b32(m.sub(NL - 1), S(self.s_lm), X.lo()); yield
                 g.v_lshrrev_b32(chy.t1, LB, X.lo()); yield          # top
@@ -241,8 +216,7 @@ class FieldGen:
             # X's low 29 bits move over to Y (52 products + 2^29 still fit 64 bits), X >> 29 waits; Y closes the column as a
             # single chain does; the next column starts from (X >> 29) + (Y >> 29).
             g.v_and_b32(chx.t0, S(self.s_lm), X.lo()); yield
-            g.v_alignbit_b32(X.lo(), X.hi(), X.lo(), LB); yield
-            g.v_lshrrev_b32(X.hi(), LB, X.hi()); yield
+            g.v_lshrrev_b64(X, LB, X); yield
             g.v_mad_u64_u32(Y, chy.sdum, chx.t0, 1, Y); yield
             if k < NL:
                 g.v_mul_lo_u32(chx.t0, Y.lo(), S(self.s_inv)); yield
@@ -250,8 +224,7 @@ class FieldGen:
                 g.v_mad_u64_u32(Y, chy.sdum, m.sub(k), self.sP(0), Y); yield
             else:
                 g.v_and_b32(m.sub(k - NL), S(self.s_lm), Y.lo()); yield
-            g.v_alignbit_b32(Y.lo(), Y.hi(), Y.lo(), LB); yield
-            g.v_lshrrev_b32(Y.hi(), LB, Y.hi()); yield
+            g.v_lshrrev_b64(Y, LB, Y); yield
             g.v_lshl_add_u64(X, Y, 0, X); yield
         # value = m + top 2^754 < 2.33 p: subtract p where top is set or m >= p, then the usual conditional subtraction
         bw, x = chx.t1, chx.t0
@@ -287,8 +260,7 @@ class FieldGen:
             g.v_mad_i64_i32(acc, ch.sdum, nq, self.sP(i), acc); yield
             g.v_and_b32(dst.sub(i), S(self.s_lm), acc.lo()); yield
             if i + 1 < NL:
-                g.v_alignbit_b32(acc.lo(), acc.hi(), acc.lo(), LB); yield
-                g.v_ashrrev_i32(acc.hi(), LB, acc.hi()); yield
+                g.v_ashrrev_i64(acc, LB, acc); yield
 
     def invc_bits(self):
         """the double 1 / (p_25 + 1) as (lo, hi) words"""

@@ -1,12 +1,12 @@
 """microbench.py -- the Montgomery product peak of the card, measured by the library itself (gh_measure_fpmul_peak).
 
 One kernel: every lane runs `iters` x two independent rr29 products (field.py mul: 2 x 26^2 v_mad_u64_u32 + one conditional
-subtraction each, fp29.h fp_mul = algebra/src/fields/models/fp_768.rs:1009-1185 mul_assign), interleaved instruction by
-instruction on two accumulator chains, on the register plan of the hot kernels (256 VGPRs, two waves per SIMD).  bench.py
+subtraction each, fp29.h fp_mul = algebra/src/fields/models/fp_768.rs:1009-1185 mul_assign), one after the other (the fastest form measured: tools/asm_mb,
+mul_seq2 against mul_pair), on the register plan of the hot kernels (256 VGPRs, two waves per SIMD).  bench.py
 reports the rate next to the round-1 constant (23.4 G products/s, tools/microbench/mb.hip) that `valu.frac` is priced against.
 """
 from .isa import Prog, V, S, fix_hazards
-from .field import FieldGen, Chain, interleave, NL, LM
+from .field import FieldGen, Chain, run, NL, LM
 
 
 def build(name, p):
@@ -29,7 +29,8 @@ def build(name, p):
     g.s_waitcnt(lgkmcnt=0)
     L, Lx = g.uniq("loop"), g.uniq("exit")
     g.label(L)
-    interleave(f.mul(A, E[2], E[0], E[4], E[2]), f.mul(B, E[3], E[1], E[5], E[3]))
+    run(f.mul(A, E[2], E[0], E[4], E[2]))          # two products, one after the other: the fastest form measured (tools/asm_mb)
+    run(f.mul(B, E[3], E[1], E[5], E[3]))
     g.s_sub_u32(S(3), S(3), 1)
     g.s_cmp_lg_u32(S(3), 0)
     g.s_cbranch_scc0(Lx)

@@ -394,6 +394,13 @@ def _lshr64(w, i):
     w.wr64(d, np.asarray(w.rd64(a), dtype=U64) >> (np.asarray(w.rd(sh)).astype(U64) & U64(63)))
 
 
+@op("v_ashrrev_i64")
+def _ashr64(w, i):
+    d, sh, a = i.args
+    v = np.asarray(w.rd64(a), dtype=U64).astype(np.int64) >> (np.asarray(w.rd(sh)).astype(np.int64) & np.int64(63))
+    w.wr64(d, v.astype(U64))
+
+
 @op("v_lshlrev_b64")
 def _lshl64(w, i):
     d, sh, a = i.args

@@ -9,6 +9,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <vector>
 
 extern "C" const unsigned char gh_asm_hsaco[];
 extern "C" const unsigned char gh_asm_hsaco_end[];
@@ -39,7 +40,21 @@ int load_locked() {
         return GH_E_HIP;
     }
     hipModule_t m = nullptr;
-    hipError_t e = hipModuleLoadData(&m, gh_asm_hsaco);
+    hipError_t e;
+    // GH_ASM_HSACO=<file>: another build of the same kernels (asmgen/build.py) instead of the embedded one -- A/B runs of
+    // generator variants on one card in one process start (measurement knob; the default is the embedded code object)
+    static std::vector<char> override_co;
+    if (const char* path = getenv("GH_ASM_HSACO")) {
+        FILE* fco = fopen(path, "rb");
+        if (!fco) { g_err = std::string("GH_ASM_HSACO: cannot open ") + path; return GH_E_BAD_ARG; }
+        char buf[65536];
+        size_t got;
+        while ((got = fread(buf, 1, sizeof buf, fco)) > 0) override_co.insert(override_co.end(), buf, buf + got);
+        fclose(fco);
+        e = hipModuleLoadData(&m, override_co.data());
+    } else {
+        e = hipModuleLoadData(&m, gh_asm_hsaco);
+    }
     if (e != hipSuccess) {
         g_err = std::string("hipModuleLoadData(assembly kernels) failed: ") + hipGetErrorString(e);
         return GH_E_HIP;

@@ -276,6 +276,128 @@ def _(g, f, A, B):
     return 1
 
 
+# ---- single instruction classes (independent instructions on eight register sets: what one instruction costs to issue)
+def _class_block(emit, n=2048):
+    def blk(g, f, A, B):
+        for k in range(n):
+            emit(g, f, k)
+        return 1
+    return blk
+
+
+BLOCKS["ic_mad_u64"] = _class_block(lambda g, f, k: g.v_mad_u64_u32(V(30 + 2 * (k % 4), 2), S(14, 2), E[2].sub(k % 26), E[0].sub((k * 7) % 26), V(30 + 2 * (k % 4), 2)))
+BLOCKS["ic_mul_lo"] = _class_block(lambda g, f, k: g.v_mul_lo_u32(V(30 + (k % 8)), E[2].sub(k % 26), E[0].sub((k * 7) % 26)))
+BLOCKS["ic_mul_lo_sgpr"] = _class_block(lambda g, f, k: g.v_mul_lo_u32(V(30 + (k % 8)), E[2].sub(k % 26), S(g1_xyzz.S_INV)))
+BLOCKS["ic_lshr64"] = _class_block(lambda g, f, k: g.v_lshrrev_b64(V(30 + 2 * (k % 4), 2), 29, V(E[2].idx + 2 * (k % 12), 2)))
+BLOCKS["ic_alignbit"] = _class_block(lambda g, f, k: g.v_alignbit_b32(V(30 + (k % 8)), E[2].sub(k % 26), E[0].sub((k * 7) % 26), 29))
+BLOCKS["ic_and"] = _class_block(lambda g, f, k: g.v_and_b32(V(30 + (k % 8)), S(g1_xyzz.S_LM), E[0].sub((k * 7) % 26)))
+BLOCKS["ic_add3"] = _class_block(lambda g, f, k: g.v_add3_u32(V(30 + (k % 8)), E[2].sub(k % 26), E[0].sub((k * 7) % 26), E[1].sub(k % 26)))
+BLOCKS["ic_lshl_add_u64"] = _class_block(lambda g, f, k: g.v_lshl_add_u64(V(30 + 2 * (k % 4), 2), V(E[2].idx + 2 * (k % 12), 2), 0, V(E[3].idx + 2 * (k % 12), 2)))
+BLOCKS["ic_cndmask"] = _class_block(lambda g, f, k: g.v_cndmask_b32(V(30 + (k % 8)), E[2].sub(k % 26), E[0].sub((k * 7) % 26), S(78, 2)))
+BLOCKS["ic_bfe"] = _class_block(lambda g, f, k: g.v_bfe_u32(V(30 + (k % 8)), E[2].sub(k % 26), 3, 29))
+
+
+@block("close_low_pair_mad")
+def _(g, f, A, B):
+    # the column closing with the m digit from a v_mad_u64_u32 (low word) instead of v_mul_lo_u32, and one 64-bit shift
+    def close(ch, m, k, tmp):
+        g.v_mad_u64_u32(tmp, ch.sdum, ch.acc.lo(), S(f.s_inv), 0); yield
+        g.v_and_b32(m.sub(k), S(f.s_lm), tmp.lo()); yield
+        g.v_mad_u64_u32(ch.acc, ch.sdum, m.sub(k), f.sP(0), ch.acc); yield
+        g.v_lshrrev_b64(ch.acc, 29, ch.acc); yield
+    for _ in range(10):
+        for k in range(NL):
+            interleave(close(A, E[4], k, V(30, 2)), close(B, E[5], k, V(32, 2)))
+    return 20
+
+
+class _OldCloseGen(FieldGen):
+    """field.py before the 64-bit shifts: v_alignbit_b32 + v_lshrrev_b32 per column (A/B block)"""
+    def _close_low(self, ch, m, k):
+        g = self.g
+        g.v_mul_lo_u32(ch.t0, ch.acc.lo(), S(self.s_inv)); yield
+        g.v_and_b32(m.sub(k), S(self.s_lm), ch.t0); yield
+        g.v_mad_u64_u32(ch.acc, ch.sdum, m.sub(k), self.sP(0), ch.acc); yield
+        g.v_alignbit_b32(ch.acc.lo(), ch.acc.hi(), ch.acc.lo(), 29); yield
+        g.v_lshrrev_b32(ch.acc.hi(), 29, ch.acc.hi()); yield
+
+    def _close_high(self, ch, r, k, last_unmasked=False):
+        g = self.g
+        if k == 2 * NL - 1:
+            g.v_and_b32(r.sub(k - NL), S(self.s_lm), ch.acc.lo()); yield
+            return
+        g.v_and_b32(r.sub(k - NL), S(self.s_lm), ch.acc.lo()); yield
+        g.v_alignbit_b32(ch.acc.lo(), ch.acc.hi(), ch.acc.lo(), 29); yield
+        g.v_lshrrev_b32(ch.acc.hi(), 29, ch.acc.hi()); yield
+
+
+@block("mul_pair_oldclose")
+def _(g, f, A, B):
+    fo = _OldCloseGen(g, f.p, f.s_p, f.s_np, f.s_inv, f.s_lm)
+    interleave(fo.mul(A, E[2], E[0], E[4], E[2]), fo.mul(B, E[3], E[1], E[5], E[3]))
+    return 2
+
+
+@block("mul_single_oldclose")
+def _(g, f, A, B):
+    fo = _OldCloseGen(g, f.p, f.s_p, f.s_np, f.s_inv, f.s_lm)
+    run(fo.mul(A, E[2], E[0], E[4], E[2]))
+    return 1
+
+
+@block("dual_one_chain")
+def _(g, f, A, B):
+    # a b + c d on ONE accumulator: every mad takes its addend from its predecessor
+    a, b, c, d, m, dd = E[5], E[2], E[6], E[4], E[7], E[6]
+    def terms(k):
+        lo, hi = max(0, k - NL + 1), min(k, NL - 1)
+        return [(a.sub(i), b.sub(k - i)) for i in range(lo, hi + 1)] + [(c.sub(i), d.sub(k - i)) for i in range(lo, hi + 1)]
+    run(f.mont_columns(A, terms, m))
+    run(f.cond_sub(A, m, dd, m))
+    return 1
+
+
+@block("g2_triple_seq")
+def _(g, f, A, B):
+    # the triple product with its two chains issued one after the other inside a column instead of alternating
+    import types
+    pairs = [(E[0], E[3]), (E[1], E[4]), (E[2], E[5])]
+    m, dd = E[6], E[7]
+    (a, b), (c, d), (e, ff) = pairs
+    X, Y = A.acc, B.acc
+    fx = True
+    for k in range(2 * NL):
+        lo, hi = max(0, k - NL + 1), min(k, NL - 1)
+        xs, ys = [], []
+        for i in range(lo, hi + 1):
+            xs.append((a.sub(i), b.sub(k - i))); xs.append((c.sub(i), d.sub(k - i))); ys.append((e.sub(i), ff.sub(k - i)))
+        mlo = 0 if k < NL else k - NL + 1
+        mhi = k - 1 if k < NL else NL - 1
+        for i in range(mlo, mhi + 1):
+            ys.append((m.sub(i), f.sP(k - i)))
+        fy = True
+        for x, y in xs:
+            g.v_mad_u64_u32(X, A.sdum, x, y, 0 if fx else X); fx = False
+        for x, y in ys:
+            g.v_mad_u64_u32(Y, B.sdum, x, y, 0 if fy else Y); fy = False
+        if k == 2 * NL - 1:
+            g.v_and_b32(m.sub(NL - 1), S(f.s_lm), X.lo())
+            g.v_lshrrev_b32(B.t1, 29, X.lo())
+            break
+        g.v_and_b32(A.t0, S(f.s_lm), X.lo())
+        g.v_lshrrev_b64(X, 29, X)
+        g.v_mad_u64_u32(Y, B.sdum, A.t0, 1, Y)
+        if k < NL:
+            g.v_mul_lo_u32(A.t0, Y.lo(), S(f.s_inv))
+            g.v_and_b32(m.sub(k), S(f.s_lm), A.t0)
+            g.v_mad_u64_u32(Y, B.sdum, m.sub(k), f.sP(0), Y)
+        else:
+            g.v_and_b32(m.sub(k - NL), S(f.s_lm), Y.lo())
+        g.v_lshrrev_b64(Y, 29, Y)
+        g.v_lshl_add_u64(X, Y, 0, X)
+    return 1
+
+
 def _phase_block(pa, pb, pm, beta, kind="mul"):
     # slots with base register = pa / pb / pm (mod 4), accumulator pair at bank beta
     bases = {0: [40, 68, 96], 2: [126, 154, 182], 1: [41 + 170, 0, 0], 3: [0, 0, 0]}
