@@ -6,10 +6,13 @@ algebra/src/fields/models/fp_768.rs:1009-1185 mul_assign + mont_reduce, :339-548
 :870-883 neg): tests/test_asmgen.py runs them in sim.py against Python integers.
 
 A "slot" is a Reg range of 26 VGPRs.  Every routine is a Python generator that yields after each emitted instruction, so
-that two independent routines can be interleaved instruction by instruction (`interleave`): a v_mad_u64_u32 that depends on
-its predecessor costs ~5 cycles, one that does not 4 (tools/microbench/lone_wave.hip: 3.40 us per product with one chain per
-wave, 2.80 us with two).  Each chain owns an accumulator pair, two temporaries, a dummy carry-out pair for the mads and a
-carry pair for borrow chains (VCC is never used inside a routine, so the two chains cannot disturb each other).
+that two independent routines can be interleaved instruction by instruction (`interleave`) -- worth it for the short carry
+chains through SGPRs (sub, masks: they wait on the SGPR hazard), NOT for products: at two waves per SIMD a v_mad_u64_u32
+that takes its addend from its predecessor issues in 4 cycles, one that alternates with another accumulator in 5
+(tools/asm_mb: mul_seq2 / dual_one_chain / g2_triple_seq against their interleaved forms, 1.6 - 5.4 %; the round-2
+measurement that said otherwise, tools/microbench/lone_wave.hip, had one wave on the card).  Each chain owns an
+accumulator pair, two temporaries, a dummy carry-out pair for the mads and a carry pair for borrow chains (VCC is never
+used inside a routine, so two interleaved chains cannot disturb each other).
 
 gfx9 constant-bus rule (ONE SGPR or literal per VALU instruction, an SGPR carry-in included) shapes the sequences: a
 borrow chain cannot take p_i from an SGPR, so the conditional subtraction runs on signed limbs with the borrow in a VGPR.

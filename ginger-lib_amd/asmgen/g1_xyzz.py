@@ -12,8 +12,8 @@ Register plan (256 VGPRs = two waves per SIMD, 0 bytes of scratch):
   X, V = sigma Y and (between two steps) R^2 of the running sum are parked in LDS, word-major: park[3][26][256].
 The prime, -p, the Montgomery constant and the limb mask live in SGPRs.
 
-Products are issued in PAIRS, interleaved instruction by instruction on the two chains:
-  (U2 || S2)  P, W  (PP || RR)  park RR  (PPP || ZZ3)  (Q || ZZZ3)  X3, T  dual(W T + V PPP)
+Order of the products (each one chain of mads, pairs back to back -- `seq`; the subtractions of a pair stay interleaved):
+  U2, S2  P, W  PP, RR  park RR  PPP, ZZ3  Q, ZZZ3  X3, T  dual(W T + V PPP)
 """
 from .isa import Prog, V, S, VCC, EXEC, OFF, fix_hazards
 from .field import FieldGen, Chain, interleave, run, NL, LM

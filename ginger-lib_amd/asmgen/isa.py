@@ -4,8 +4,9 @@ can be (a) printed as assembler text for clang -x assembler -mcpu=gfx950 and (b)
 Why hand-allocated assembly: the Montgomery product kernels are register-allocation bound under
 hipcc (spills in the G1 update, one wave per SIMD and an out-of-line call ABI for the towers).  Here every field element
 has a fixed home (a "slot" of 26 consecutive VGPRs, or AGPRs), the prime lives in SGPRs, and the instruction order is
-the generator's: two independent accumulator chains are interleaved instruction by instruction, which is what the
-v_mad_u64_u32 pipeline needs to issue every 4 cycles (tools/microbench/lone_wave.hip).
+the generator's: a product is ONE chain of v_mad_u64_u32, each taking its 64-bit addend from its predecessor (which the
+pipeline forwards: 4 cycles per mad; alternating two accumulators costs a fifth cycle for the register-file read of the
+addend -- tools/asm_mb).
 
 Operands:  V(i) / V(i, n)  VGPR or VGPR range;  A(i) AGPR;  S(i) / S(i, n) SGPR (range);  an int = immediate;
            VCC, EXEC;  a str = label.
