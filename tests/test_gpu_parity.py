@@ -79,6 +79,49 @@ def test_ntt_full_size_roundtrips(gpu):
     assert (got == S.oracle_fft("mnt4753_fr", a, log_n, 2, 16)).all()
 
 
+
+def test_assembly_pass_and_cpp_pass_give_the_same_vectors(gpu):
+    """The generated NTT pass (asmgen/ntt_pass.py) and the hipcc pass (ntt_kernels.h) are interchangeable: a child process with
+    GH_NTT_ASM=0 runs the same four transforms on the same seeded inputs; the vectors must be equal bit for bit (2^13: passes of 7 + 6
+    stages; 2^17: 6 + 6 + 5, a pass of each kind inside ONE transform; 2^20: the prover's domain)."""
+    import subprocess
+    import sys
+    import tempfile
+    import zlib
+    script = r"""
+import os, sys, zlib, json
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np, pyref, support as S
+from __graft_entry__ import _load_pkg
+gl = _load_pkg(); gl.init()
+out = {}
+for log_n in (13, 17, 20):
+    n = 1 << log_n
+    a = S.random_scalars_np(n, seed=40 + log_n, below=pyref.P6.p)
+    dom = gl.EvaluationDomain("mnt4753_fr", n)
+    buf = gl.DeviceBuffer(n * 96).upload(a)
+    for fl in (0, 2, 3, 1):
+        dom.fft_dev(buf, fl)
+        out["%%d_%%d" %% (log_n, fl)] = zlib.crc32(buf.download().tobytes())
+    buf.free()
+print("CRC " + json.dumps(out, sort_keys=True))
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GH_NTT_ASM="0")
+    p = subprocess.run([sys.executable, "-c", script], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("CRC ")][-1]
+    ref = json.loads(line[4:])
+    for log_n in (13, 17, 20):
+        n = 1 << log_n
+        a = S.random_scalars_np(n, seed=40 + log_n, below=pyref.P6.p)
+        dom = gpu.EvaluationDomain("mnt4753_fr", n)
+        buf = gpu.DeviceBuffer(n * 96).upload(a)
+        for fl in (0, 2, 3, 1):
+            dom.fft_dev(buf, fl)
+            assert zlib.crc32(buf.download().tobytes()) == ref["%d_%d" % (log_n, fl)], (log_n, fl)
+        buf.free()
+
+
 def test_vec_ops(gpu):
     F = pyref.P6
     n = 1000
