@@ -60,7 +60,9 @@ int ensure_init() {
         };
         HIPCHK(hipStreamCreateWithPriority(&g.stream_acc, hipStreamDefault, prio("GH_PRIO_ACC", least)));
         HIPCHK(hipStreamCreateWithPriority(&g.stream_red, hipStreamDefault, prio("GH_PRIO_RED", greatest)));
+        HIPCHK(hipStreamCreateWithPriority(&g.stream_acc2, hipStreamDefault, prio("GH_PRIO_ACC", least)));
     }
+    for (auto& ev : g.tev) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     for (auto& ev : g.ev) HIPCHK(hipEventCreate(&ev));
     for (auto& sl : g.pev) for (auto& ev : sl) HIPCHK(hipEventCreate(&ev));
     g.ready = true;
@@ -231,6 +233,7 @@ int gh_shutdown(void) try {
     if (!g.ready) return GH_OK;
     hipStreamSynchronize(g.stream);
     hipStreamSynchronize(g.stream_acc);
+    hipStreamSynchronize(g.stream_acc2);
     hipStreamSynchronize(g.stream_red);
     for (auto& kv : g.pool) if (kv.second.p) hipFree(kv.second.p);
     g.pool.clear();
@@ -250,7 +253,9 @@ int gh_shutdown(void) try {
     }
     for (auto& ev : g.ev) hipEventDestroy(ev);
     for (auto& sl : g.pev) for (auto& ev : sl) hipEventDestroy(ev);
+    for (auto& ev : g.tev) hipEventDestroy(ev);
     hipStreamDestroy(g.stream_acc);
+    hipStreamDestroy(g.stream_acc2);
     hipStreamDestroy(g.stream_red);
     hipStreamDestroy(g.stream);
     g.scratch_reserved = 0;

@@ -949,14 +949,81 @@ struct MsmJob {
         const uint32_t asm_max_waves = (uint32_t)g.num_cus * 4u * 2u * (uint32_t)(env_wmul > 0 && env_wmul <= 16 ? env_wmul : 1);
         void* asm_accs = nullptr;
         uint32_t* asm_flag = nullptr;
+        // Two copies of the per-round control data: a large round is issued as two halves (below)
+        const size_t accs_half = t64_bytes((size_t)asm_max_waves + 4, T64_FP_CHUNKS);
+        const size_t flag_words = 16 + (size_t)AFF_FIX_CAP;
         if (aff_asm) {
             snprintf(nm, sizeof nm, "aff_accs#%d", slot);
-            if ((rc = pool_get(nm, t64_bytes((size_t)asm_max_waves + 4, T64_FP_CHUNKS), &asm_accs))) return rc;
+            if ((rc = pool_get(nm, 2 * accs_half, &asm_accs))) return rc;
             snprintf(nm, sizeof nm, "aff_flag#%d", slot);
-            if ((rc = pool_get(nm, 64 + 4 * (size_t)AFF_FIX_CAP, (void**)&asm_flag))) return rc;   // control block + exception list
+            if ((rc = pool_get(nm, 2 * 4 * flag_words, (void**)&asm_flag))) return rc;   // control block + exception list, per half
             HIPCHK(hipMemsetAsync(asm_flag, 0, 64, st));                    // word 4: "a round of this MSM was redone" (sticky)
+            HIPCHK(hipMemsetAsync(asm_flag + flag_words, 0, 64, st));
         }
+        // A round = forward kernel, tower inversion of the lane groups' running products, backward kernel.  The inversion is
+        // 0.4 ms of latency with the card nearly idle.  A large round therefore goes out as two halves of its output range on two
+        // streams, the second half one kernel behind the first: the inversion of either half runs beside a forward / backward
+        // kernel of the other (GH_AFF_SPLIT=0: one piece; halves are whole tiles, so every list keeps its layout).
+        static const int env_split = getenv("GH_AFF_SPLIT") ? atoi(getenv("GH_AFF_SPLIT")) : 1;
+        static const int env_split_b = getenv("GH_AFF_SPLIT_B") ? atoi(getenv("GH_AFF_SPLIT_B")) : 32;   // smallest batch per lane group worth splitting
         const Aff<C>* rows = (const Aff<C>*)(merged ? h->d_table : h->d_points);
+        // one piece of a round: outputs [o0, o0 + n_piece) (o0 a multiple of the tile size); which: 0 / 1 = control block, stream role
+        struct Piece {
+            AffRoundArgs<C> a;
+            gh_asm::AffArgs q;
+            uint32_t waves_cpp, aw, Bq;
+            uint32_t* flag;
+            void* accs;
+        };
+        auto make_piece = [&](int r, uint32_t j, size_t doff, const void* in, void* out, uint32_t o0, uint32_t n_piece, int which) {
+            Piece P;
+            const size_t t0 = o0 / TPW;                                    // first tile of the piece in every list
+            auto off = [&](void* base, int chunks) { return (void*)((char*)base + t64_bytes(t0, chunks)); };
+            uint32_t waves = (n_piece + TPW * (uint32_t)env_bmin - 1) / (TPW * (uint32_t)env_bmin);
+            if (waves > max_waves) waves = max_waves;
+            waves = (waves + 3u) & ~3u;
+            AffRoundArgs<C>& a = P.a;
+            a.rows = rows; a.in = in; a.sorted = r == 0 ? sorted : nullptr; a.desc = desc + doff + o0; a.n_out = n_piece; a.in_base = T(j, r);
+            a.prefix = off(prefix, T64_FP_CHUNKS); a.out = off(out, T64_PT_CHUNKS);
+            a.stage1 = off(stage1, T64_PT_CHUNKS); a.stage2 = off(stage2, T64_PT_CHUNKS);
+            a.groups = waves * TPW; a.bmin = (uint32_t)env_bmin;
+            a.run_if = nullptr;
+            P.waves_cpp = waves;
+            uint32_t aw = (n_piece + TPW * (uint32_t)env_bmin - 1) / (TPW * (uint32_t)env_bmin);
+            if (aw > asm_max_waves) aw = asm_max_waves;
+            aw = (aw + 3u) & ~3u;
+            uint32_t Bq = (n_piece + aw * TPW - 1) / (aw * TPW);
+            if (Bq < (uint32_t)env_bmin) Bq = (uint32_t)env_bmin;
+            P.aw = aw; P.Bq = Bq;
+            P.flag = asm_flag ? asm_flag + (size_t)which * flag_words : nullptr;
+            P.accs = asm_accs ? (void*)((char*)asm_accs + (size_t)which * accs_half) : nullptr;
+            gh_asm::AffArgs& q = P.q;
+            q.in = r == 0 ? (const void*)rows : in; q.sorted = sorted; q.desc = a.desc; q.prefix = a.prefix;
+            q.stage1 = a.stage1; q.stage2 = a.stage2; q.out = a.out; q.accs = P.accs; q.flag = P.flag;
+            q.n_out = n_piece; q.in_base = T(j, r); q.B = Bq; q.pad = 0;
+            return P;
+        };
+        // The assembly kernels (asmgen/g2_rounds.py): forward pass, tower inversion of the lane groups' running products, backward
+        // pass -- 256 registers, two waves per SIMD, no scratch, no out-of-line product.  Elements on the group law's rare branches
+        // go through an exception list (aff_fix_kernel); only if the list overflowed, the whole piece once more on the C++ kernel.
+        auto issue_fwd = [&](Piece& P, int r, hipStream_t s_) -> int {
+            HIPCHK(hipMemsetAsync(P.flag, 0, 16, s_));
+            return gh_asm::aff_launch(asm_kind, true, r == 0, P.q, P.aw, s_);
+        };
+        auto issue_rest = [&](Piece& P, int r, hipStream_t s_) -> int {
+            int rc2;
+            GH_LAUNCH((aff_inv_kernel<FS>), dim3(P.aw / 4), dim3(256), 0, s_, P.accs, P.aw, P.a.n_out, P.Bq, (const uint32_t*)P.flag);
+            if ((rc2 = gh_asm::aff_launch(asm_kind, false, r == 0, P.q, P.aw, s_))) return rc2;
+            if (r == 0) GH_LAUNCH((aff_fix_kernel<C, FS, true>), dim3(16), dim3(256), 0, s_, P.a, (const uint32_t*)P.flag);
+            else GH_LAUNCH((aff_fix_kernel<C, FS, false>), dim3(16), dim3(256), 0, s_, P.a, (const uint32_t*)P.flag);
+            P.a.run_if = P.flag;
+            return GH_OK;
+        };
+        auto issue_cpp = [&](Piece& P, int r, hipStream_t s_) -> int {   // the C++ round kernel: the whole piece, or (run_if) its fallback
+            if (r == 0) GH_LAUNCH((aff_round_kernel<C, FS, true>), dim3(P.waves_cpp / 4), dim3(256), 0, s_, P.a);
+            else GH_LAUNCH((aff_round_kernel<C, FS, false>), dim3(P.waves_cpp / 4), dim3(256), 0, s_, P.a);
+            return GH_OK;
+        };
         for (uint32_t j = 0; j < K; j++) {
             size_t doff = 0;
             const void* in = nullptr;
@@ -964,54 +1031,50 @@ struct MsmJob {
                 const uint32_t n_out = T(j + 1, r + 1) - T(j, r + 1);
                 void* out = (r & 1) ? ptsB : ptsA;
                 if (n_out > 0) {
-                    const uint32_t* st_in = r == 0 ? starts : aff_st + (size_t)(r - 1) * stride;
-                    const uint32_t* m_in = r == 0 ? counts : aff_cnt + (size_t)(r - 1) * stride;
                     unsigned dgrid = (n_out + 255) / 256;
                     if (dgrid > 16384) dgrid = 16384;
+                    const uint32_t* st_in = r == 0 ? starts : aff_st + (size_t)(r - 1) * stride;
+                    const uint32_t* m_in = r == 0 ? counts : aff_cnt + (size_t)(r - 1) * stride;
                     GH_LAUNCH(aff_desc_kernel, dim3(dgrid), dim3(256), 0, st, st_in, m_in,
                                        (const uint32_t*)(aff_st + (size_t)r * stride), (uint32_t)total, T(j, r + 1), n_out, desc + doff);
-                    uint32_t waves = (n_out + TPW * (uint32_t)env_bmin - 1) / (TPW * (uint32_t)env_bmin);
-                    if (waves > max_waves) waves = max_waves;
-                    waves = (waves + 3u) & ~3u;
-                    AffRoundArgs<C> a;
-                    a.rows = rows; a.in = in; a.sorted = r == 0 ? sorted : nullptr; a.desc = desc + doff; a.n_out = n_out; a.in_base = T(j, r);
-                    a.prefix = prefix; a.out = out; a.stage1 = stage1; a.stage2 = stage2; a.groups = waves * TPW; a.bmin = (uint32_t)env_bmin;
-                    a.run_if = nullptr;
-                    {
-                        if (aff_asm) {
-                            // The assembly kernels (asmgen/g2_rounds.py): forward pass, tower inversion of the lane groups' running
-                            // products, backward pass -- 256 registers, two waves per SIMD, no scratch, no out-of-line product.
-                            // Elements on the group law's rare branches go through an exception list (aff_fix_kernel).
-                            uint32_t aw = (n_out + TPW * (uint32_t)env_bmin - 1) / (TPW * (uint32_t)env_bmin);
-                            if (aw > asm_max_waves) aw = asm_max_waves;
-                            aw = (aw + 3u) & ~3u;
-                            uint32_t Bq = (n_out + aw * TPW - 1) / (aw * TPW);
-                            if (Bq < (uint32_t)env_bmin) Bq = (uint32_t)env_bmin;
-                            gh_asm::AffArgs q;
-                            q.in = r == 0 ? (const void*)rows : in; q.sorted = sorted; q.desc = desc + doff; q.prefix = prefix;
-                            q.stage1 = stage1; q.stage2 = stage2; q.out = out; q.accs = asm_accs; q.flag = asm_flag;
-                            q.n_out = n_out; q.in_base = T(j, r); q.B = Bq; q.pad = 0;
-                            HIPCHK(hipMemsetAsync(asm_flag, 0, 16, st));
-                            if ((rc = gh_asm::aff_launch(asm_kind, true, r == 0, q, aw, st))) return rc;
-                            GH_LAUNCH((aff_inv_kernel<FS>), dim3(aw / 4), dim3(256), 0, st, asm_accs, aw, n_out, Bq, (const uint32_t*)asm_flag);
-                            if ((rc = gh_asm::aff_launch(asm_kind, false, r == 0, q, aw, st))) return rc;
-                            // the listed exceptions (doubling, cancellation, markers), one lane group each; then, only if the list
-                            // overflowed, the whole round once more on the C++ kernel
-                            if (r == 0) GH_LAUNCH((aff_fix_kernel<C, FS, true>), dim3(16), dim3(256), 0, st, a, (const uint32_t*)asm_flag);
-                            else GH_LAUNCH((aff_fix_kernel<C, FS, false>), dim3(16), dim3(256), 0, st, a, (const uint32_t*)asm_flag);
-                            a.run_if = asm_flag;
-                            static const bool aff_debug = getenv("GH_AFF_DEBUG") != nullptr;
-                            if (aff_debug) {      // how many elements of the round went through the exception list / whether it overflowed
-                                uint32_t fw[4] = {0, 0, 0, 0};
-                                HIPCHK(hipStreamSynchronize(st));
-                                HIPCHK(hipMemcpy(fw, asm_flag, 16, hipMemcpyDeviceToHost));
-                                fprintf(stderr, "[gh aff] chunk %u round %d n_out %u waves %u B %u in_base %u redo %u exceptions %u\n", j, r, n_out, aw, Bq,
-                                        q.in_base, fw[0], fw[1]);
-                            }
-                        }
+                    // halves: whole tiles, the first one a multiple of four tiles
+                    uint32_t nA = ((n_out / 2 + 4 * TPW - 1) / (4 * TPW)) * (4 * TPW);
+                    bool split = aff_asm && env_split != 0 && nA < n_out;
+                    if (split) {
+                        const uint32_t whole = (uint32_t)(((size_t)n_out + (size_t)asm_max_waves * TPW - 1) / ((size_t)asm_max_waves * TPW));
+                        split = whole >= (uint32_t)env_split_b;          // batch per lane group if the round went out in one piece
                     }
-                    if (r == 0) GH_LAUNCH((aff_round_kernel<C, FS, true>), dim3(waves / 4), dim3(256), 0, st, a);
-                    else GH_LAUNCH((aff_round_kernel<C, FS, false>), dim3(waves / 4), dim3(256), 0, st, a);
+                    if (!aff_asm) {
+                        Piece P = make_piece(r, j, doff, in, out, 0, n_out, 0);
+                        if ((rc = issue_cpp(P, r, st))) return rc;
+                    } else if (!split) {
+                        Piece P = make_piece(r, j, doff, in, out, 0, n_out, 0);
+                        if ((rc = issue_fwd(P, r, st))) return rc;
+                        if ((rc = issue_rest(P, r, st))) return rc;
+                        static const bool aff_debug = getenv("GH_AFF_DEBUG") != nullptr;
+                        if (aff_debug) {      // how many elements of the round went through the exception list / whether it overflowed
+                            uint32_t fw[4] = {0, 0, 0, 0};
+                            HIPCHK(hipStreamSynchronize(st));
+                            HIPCHK(hipMemcpy(fw, P.flag, 16, hipMemcpyDeviceToHost));
+                            fprintf(stderr, "[gh aff] chunk %u round %d n_out %u waves %u B %u in_base %u redo %u exceptions %u\n", j, r, n_out, P.aw, P.Bq,
+                                    P.q.in_base, fw[0], fw[1]);
+                        }
+                        if ((rc = issue_cpp(P, r, st))) return rc;
+                    } else {
+                        Piece A = make_piece(r, j, doff, in, out, 0, nA, 0);
+                        Piece B = make_piece(r, j, doff, in, out, nA, n_out - nA, 1);
+                        hipStream_t st2 = g.stream_acc2;
+                        if ((rc = issue_fwd(A, r, st))) return rc;
+                        HIPCHK(hipEventRecord(g.tev[0], st));                 // the round's inputs are complete and A's forward pass is out
+                        HIPCHK(hipStreamWaitEvent(st2, g.tev[0], 0));
+                        if ((rc = issue_fwd(B, r, st2))) return rc;
+                        if ((rc = issue_rest(A, r, st))) return rc;
+                        if ((rc = issue_rest(B, r, st2))) return rc;
+                        if ((rc = issue_cpp(A, r, st))) return rc;
+                        if ((rc = issue_cpp(B, r, st2))) return rc;
+                        HIPCHK(hipEventRecord(g.tev[1], st2));
+                        HIPCHK(hipStreamWaitEvent(st, g.tev[1], 0));          // join: the next round reads both halves
+                    }
                 }
                 doff += n_out;
                 in = out;
@@ -1036,6 +1099,7 @@ struct MsmJob {
         HIPCHK(hipGetLastError());
         if (aff_asm) {        // read with the window sums in finish(): a key that overflows the exception list leaves the assembly rounds
             HIPCHK(hipMemcpyAsync(&hplan[16], asm_flag + 4, 4, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipMemcpyAsync(&hplan[17], asm_flag + flag_words + 4, 4, hipMemcpyDeviceToHost, st));
             aff_sticky_pending = true;
         }
         n_heavy = 0;   // no chunk sums to combine
@@ -1134,7 +1198,7 @@ struct MsmJob {
             return GH_OK;
         }
         HIPCHK(hipEventSynchronize(g.pev[es][6]));
-        if (aff_sticky_pending && hplan[16] != 0) h->aff_asm_off = 1;
+        if (aff_sticky_pending && (hplan[16] != 0 || hplan[17] != 0)) h->aff_asm_off = 1;
         auto t_fold0 = std::chrono::steady_clock::now();
         std::vector<Proj<C>> hwv(hw, hw + (size_t)9 * RW);
         if (lean) {

@@ -1709,6 +1709,8 @@ struct P3Slab {   // run / wacc / tmp of a program, word-major per lane (see Red
     }
 };
 
+// (A 256-register build of this kernel -- two waves per SIMD, so that inside a batch a program would share its SIMD with a wave of
+// the next MSM's round kernels -- was measured at the end of round 4: 2.4 KB of scratch per lane on Fq3, batches 2-3 % SLOWER.)
 template <class C, class FS, int LANES, int TPW>
 __global__ void __launch_bounds__(64, 1)
 msm_wave_reduce_split_kernel(WaveReduceIn<C> in0, WaveReduceIn<C> in1, WaveReduceIn<C> in2, uint32_t blocks_per_input,

@@ -38,6 +38,8 @@ struct Ctx {
     hipStream_t stream = nullptr;       // transforms, bucket sort
     hipStream_t stream_acc = nullptr;   // MSM accumulation (lowest priority: the filler of the pipeline)
     hipStream_t stream_red = nullptr;   // MSM bucket reduction (highest priority: short latency chains)
+    hipStream_t stream_acc2 = nullptr;  // second half of a split affine round (msm_impl.h launch_tree): same priority as stream_acc
+    hipEvent_t tev[2] = {nullptr, nullptr};   // fork / join of a split round
     hipEvent_t ev[8];
     hipEvent_t pev[4][8];               // MSM stage events, one set per job in flight (job k of a batch uses set k & 3)
     std::map<int, Domain> domains[2];
