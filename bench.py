@@ -541,14 +541,15 @@ def main():
                 one_ms = (time.perf_counter() - t1) / KG * 1e3
                 gtm = gl.msm_last_timing()
                 gl.msm_batch_dev([(rbg, dg, ng)] * 2)            # untimed: the second pipeline slot's buffers are allocated on first use
+                KB = 10                                          # MSMs in the timed batch (its first sort and last reduction are not hidden)
                 t1 = time.perf_counter()
-                gb_out = gl.msm_batch_dev([(rbg, dg, ng)] * KG)
-                bt_ms = (time.perf_counter() - t1) * 1e3 / KG
+                gb_out = gl.msm_batch_dev([(rbg, dg, ng)] * KB)
+                bt_ms = (time.perf_counter() - t1) * 1e3 / KB
                 g_bytes = (192.0 * Cg.deg + 96.0) * ng
                 g_affine = os.environ.get("GH_AFFINE", "2") != "0"
                 g_per_add = (6 if g_affine else 11) * {2: 4, 3: 9}[Cg.deg]
                 out["g2"][crv] = {"workload": "%s VariableBaseMSM, 2^%d pairs, resident key with shift table" % (crv, lg),
-                                  "steps_per_figure": KG,
+                                  "steps_per_figure": KG, "steps_in_pipelined_batch": KB,
                                   "closed_form_ok": closed_form_ok(crv, p0g, stg, sg, g_out) and closed_form_ok(crv, p0g, stg, sg, gb_out[-1]),
                                   "roofline": {"kernel": "gh_asm_aff_* round kernels + inversion + projective finish (all accumulation launches of one MSM)", "bound": "hbm",
                                                "achieved": g_bytes / (gtm["accumulate_ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
