@@ -520,7 +520,7 @@ def main():
         except gl.GingerHipError as e:          # e.g. not enough HBM next to another tenant: the object is absent, the line stands
             out["msm_2p24"] = {"error": str(e)}
 
-    # ---- G2 (the prover's b_g2 MSM: BASELINE configs 4 / 5 shapes), one MSM at a time and as a pipelined batch of three
+    # ---- G2 (the prover's b_g2 MSM: BASELINE configs 4 / 5 shapes), one MSM at a time and as a pipelined batch of ten
     if not args.no_g2 and rank == 0 and world == 1 and curve == "mnt4753_g1" and not args.window:
         out["g2"] = {}
         for crv, lg in (("mnt4753_g2", 20), ("mnt6753_g2", 19)):
