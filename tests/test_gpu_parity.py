@@ -919,3 +919,21 @@ def test_msm_parity_again_with_the_lean_reduction_forced(gpu):
                          env=env, capture_output=True, text=True, timeout=900, cwd=root)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert " passed" in out.stdout
+
+
+def test_affine_rounds_parity_again_with_every_round_split(gpu):
+    """Large affine rounds go out as two halves on two streams (msm_impl.h launch_tree); sizes the oracle can referee stay below the
+    threshold, so the affine-round parity tests of this file run once more in a child process with GH_AFF_SPLIT_B=1 (every round with
+    more than one tile of outputs is split: ragged second halves, exception lists in both control blocks, duplicate bases that overflow
+    them) -- against the oracle as before."""
+    import os, subprocess, sys
+    if os.environ.get("GH_AFF_SPLIT_B"):
+        pytest.skip("already the forced run")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GH_AFF_SPLIT_B="1")
+    sel = ("test_msm_affine_bucket_sums_vs_oracle or test_msm_affine_degenerate_inputs or test_msm_adds_up_the_scalars_of_equal_bases or "
+           "test_g2_key_of_duplicate_bases_leaves_the_assembly_rounds or test_msm_precomputed_skewed_and_large")
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-m", "gpu", "-x", "-q", "-k", sel],
+                         env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert " passed" in out.stdout
